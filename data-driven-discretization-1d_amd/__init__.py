@@ -9,6 +9,10 @@ from . import duckarray
 from . import polynomials
 from . import equations
 from . import hparams
+from . import _lib
+from . import layers
+from . import model
+from . import integrate
 from .hparams import HParams, create_hparams, load_hparams, save_hparams
 
 __version__ = '0.1.0'

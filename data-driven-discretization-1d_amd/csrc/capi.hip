@@ -1,0 +1,813 @@
+// C ABI of libddd1d.so (include/ddd1d.h): model lifecycle, weight packing for
+// the MFMA kernels, launch dispatch.  No torch types, no exceptions across the
+// boundary.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ddd1d.h"
+#include "dev_params.h"
+#include "ops.h"
+#include "rhs_generic.h"
+#include "rhs_mfma.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return code;
+}
+
+#define DDD_HIP(expr)                                                        \
+  do {                                                                       \
+    hipError_t err__ = (expr);                                               \
+    if (err__ != hipSuccess)                                                 \
+      return fail(DDD_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                  hipGetErrorString(err__), __FILE__, __LINE__);             \
+  } while (0)
+
+template <typename T>
+int upload(const std::vector<T>& host, T** dev) {
+  *dev = nullptr;
+  if (host.empty()) return DDD_OK;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(dev), host.size() * sizeof(T)));
+  DDD_HIP(hipMemcpy(*dev, host.data(), host.size() * sizeof(T),
+                    hipMemcpyHostToDevice));
+  return DDD_OK;
+}
+
+bool is_conservative(int eq) {
+  switch (eq) {
+    case DDD_EQ_BURGERS_CONSERVATIVE: case DDD_EQ_KDV_CONSERVATIVE:
+    case DDD_EQ_KS_CONSERVATIVE: case DDD_EQ_BURGERS_GODUNOV:
+    case DDD_EQ_KDV_GODUNOV: case DDD_EQ_KS_GODUNOV:
+      return true;
+    default:
+      return false;
+  }
+}
+
+bool is_forced_family(int eq) {   // equations.py:276-277: only Burgers adds forcing(t)
+  return eq == DDD_EQ_BURGERS || eq == DDD_EQ_BURGERS_CONSERVATIVE ||
+         eq == DDD_EQ_BURGERS_GODUNOV;
+}
+
+int expected_derivatives(int eq) {
+  switch (eq) {
+    case DDD_EQ_BURGERS: case DDD_EQ_BURGERS_CONSERVATIVE: case DDD_EQ_KDV:
+    case DDD_EQ_KDV_CONSERVATIVE:
+      return 2;
+    case DDD_EQ_KS: case DDD_EQ_KS_CONSERVATIVE: case DDD_EQ_BURGERS_GODUNOV:
+    case DDD_EQ_KDV_GODUNOV:
+      return 3;
+    case DDD_EQ_KS_GODUNOV:
+      return 4;
+    default:
+      return -1;
+  }
+}
+
+int make_tableau(int scheme, ddd::Tableau* tab) {
+  std::memset(tab, 0, sizeof(*tab));
+  switch (scheme) {
+    case DDD_SCHEME_EULER:
+      tab->stages = 1; tab->b[0] = 1.0f;
+      return DDD_OK;
+    case DDD_SCHEME_MIDPOINT:   // tf.contrib.integrate.odeint_fixed 'midpoint'
+      tab->stages = 2;
+      tab->a[1] = 0.5f; tab->c[1] = 0.5;
+      tab->b[0] = 0.0f; tab->b[1] = 1.0f;
+      return DDD_OK;
+    case DDD_SCHEME_BS3:        // Bogacki-Shampine (SciPy RK23 tableau)
+      tab->stages = 3;
+      tab->a[1] = 0.5f; tab->a[2] = 0.75f;
+      tab->c[1] = 0.5; tab->c[2] = 0.75;
+      tab->b[0] = (float)(2.0 / 9.0); tab->b[1] = (float)(1.0 / 3.0);
+      tab->b[2] = (float)(4.0 / 9.0);
+      return DDD_OK;
+    case DDD_SCHEME_RK4:
+      tab->stages = 4;
+      tab->a[1] = 0.5f; tab->a[2] = 0.5f; tab->a[3] = 1.0f;
+      tab->c[1] = 0.5; tab->c[2] = 0.5; tab->c[3] = 1.0;
+      tab->b[0] = (float)(1.0 / 6.0); tab->b[1] = (float)(1.0 / 3.0);
+      tab->b[2] = (float)(1.0 / 3.0); tab->b[3] = (float)(1.0 / 6.0);
+      return DDD_OK;
+    default:
+      return fail(DDD_ERR_INVALID_ARGUMENT, "unknown scheme %d", scheme);
+  }
+}
+
+}  // namespace
+
+struct ddd_model {
+  ddd_config cfg;
+  ddd::DevParams dp;
+  bool mfma_ok = false;
+  std::string mfma_reason;
+  int kernel = DDD_KERNEL_GENERIC;   // resolved family
+  int64_t fma_per_point = 0;
+  // device allocations
+  float* d_weights = nullptr;
+  float* d_nullspace = nullptr;
+  float* d_bias = nullptr;
+  float* d_nullspace8 = nullptr;
+  float* d_bias8 = nullptr;
+  float* d_w_input = nullptr;
+  float* d_w_hidden = nullptr;
+  float* d_w_final = nullptr;
+  float4* d_frc = nullptr;
+  float* d_sp = nullptr;
+  // scratch for the per-substep launch mode
+  float* d_scratch = nullptr;
+  size_t scratch_floats = 0;
+};
+
+namespace {
+
+void free_dev(void* p) { if (p) (void)hipFree(p); }
+
+int common_config_checks(const ddd_config* cfg) {
+  if (cfg == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "cfg is NULL");
+  if (cfg->struct_size != (int32_t)sizeof(ddd_config))
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "ddd_config.struct_size = %d, library expects %d (ABI mismatch)",
+                cfg->struct_size, (int)sizeof(ddd_config));
+  const int nd = expected_derivatives(cfg->equation);
+  if (nd < 0) return fail(DDD_ERR_INVALID_ARGUMENT, "unknown equation %d", cfg->equation);
+  if (cfg->num_derivatives != nd)
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "equation %d has %d spatial derivatives, got num_derivatives = %d",
+                cfg->equation, nd, cfg->num_derivatives);
+  if (cfg->num_points < 2)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "num_points = %d", cfg->num_points);
+  if (!(cfg->dx > 0.0))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "dx must be positive");
+  if (cfg->stencil_size < 1 || cfg->stencil_size > DDD_MAX_STENCIL)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "stencil_size = %d out of range [1, %d]",
+                cfg->stencil_size, DDD_MAX_STENCIL);
+  return DDD_OK;
+}
+
+void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
+  std::memset(dp, 0, sizeof(*dp));
+  dp->equation = cfg.equation;
+  dp->N = cfg.num_points;
+  dp->D = cfg.num_derivatives;
+  dp->G = cfg.stencil_size;
+  dp->eta = (float)cfg.eta;
+  dp->stddev = (float)cfg.standard_deviation;
+  dp->inv_dx = (float)(1.0 / cfg.dx);
+  dp->conservative = is_conservative(cfg.equation) ? 1 : 0;
+}
+
+// Tables zero-padded to 8 stencil columns for the MFMA-path epilogue.
+int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias) {
+  const ddd::DevParams& dp = m->dp;
+  std::vector<float> b8((size_t)dp.D * ddd::kGMax, 0.0f);
+  for (int d = 0; d < dp.D; ++d)
+    for (int g = 0; g < dp.G; ++g) b8[d * ddd::kGMax + g] = bias[d * dp.G + g];
+  int rc = upload(b8, &m->d_bias8);
+  if (rc) return rc;
+  m->dp.bias8 = m->d_bias8;
+  if (nullspace != nullptr) {
+    int total_in = 0;
+    for (int d = 0; d < dp.D; ++d) total_in += dp.in_size[d];
+    std::vector<float> n8((size_t)total_in * ddd::kGMax, 0.0f);
+    int row = 0;
+    for (int d = 0; d < dp.D; ++d) {
+      m->dp.ns8_off[d] = row * ddd::kGMax;
+      for (int j = 0; j < dp.in_size[d]; ++j, ++row)
+        for (int g = 0; g < dp.G; ++g)
+          n8[(size_t)row * ddd::kGMax + g] = nullspace[dp.ns_off[d] + j * dp.G + g];
+    }
+    rc = upload(n8, &m->d_nullspace8);
+    if (rc) return rc;
+    m->dp.nullspace8 = m->d_nullspace8;
+  }
+  return DDD_OK;
+}
+
+// Reorder conv weights into MFMA A-operand order (rhs_mfma.h).
+int pack_mfma_weights(ddd_model* m, const float* weights) {
+  const ddd::DevParams& dp = m->dp;
+  const int hidden = dp.L - 2;
+  {
+    // input layer 1 -> 32: k = 2 s + (lane >> 5) is the tap, k = 5 the bias
+    const float* w = weights + dp.w_off[0];   // [5][1][32]
+    const float* b = weights + dp.b_off[0];
+    std::vector<float> packed((size_t)ddd::mfma::kInSteps * 64, 0.0f);
+    for (int s = 0; s < ddd::mfma::kInSteps; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int k = 2 * s + (lane >> 5), ch = lane & 31;
+        packed[s * 64 + lane] = k < 5 ? w[k * 32 + ch] : b[ch];
+      }
+    int rc = upload(packed, &m->d_w_input);
+    if (rc) return rc;
+    m->dp.w_input = m->d_w_input;
+  }
+  if (hidden > 0) {
+    std::vector<float> packed((size_t)hidden * ddd::mfma::kHidSteps * 64, 0.0f);
+    for (int h = 0; h < hidden; ++h) {
+      const float* w = weights + dp.w_off[h + 1];   // [5][32][32]
+      const float* b = weights + dp.b_off[h + 1];
+      float* dst = packed.data() + (size_t)h * ddd::mfma::kHidSteps * 64;
+      for (int s = 0; s < 80; ++s) {
+        const int tap = s / 16, jj = s % 16;
+        for (int lane = 0; lane < 64; ++lane) {
+          const int cin = 16 * (lane >> 5) + jj, cout = lane & 31;
+          dst[s * 64 + lane] = w[(tap * 32 + cin) * 32 + cout];
+        }
+      }
+      for (int lane = 0; lane < 64; ++lane)
+        dst[80 * 64 + lane] = (lane >> 5) == 0 ? b[lane & 31] : 0.0f;
+    }
+    int rc = upload(packed, &m->d_w_hidden);
+    if (rc) return rc;
+    m->dp.w_hidden = m->d_w_hidden;
+  }
+  {
+    const int l = dp.L - 1;
+    const int cout_n = dp.C_out;
+    const float* w = weights + dp.w_off[l];   // [5][32][C_out]
+    const float* b = weights + dp.b_off[l];
+    std::vector<float> packed((size_t)ddd::mfma::kFinSteps * 64, 0.0f);
+    for (int s = 0; s < 40; ++s) {
+      const int tap = s / 8, jj = s % 8;
+      for (int lane = 0; lane < 64; ++lane) {
+        const int cin = 8 * (lane >> 4) + jj, cout = lane & 15;
+        packed[s * 64 + lane] = cout < cout_n ? w[(tap * 32 + cin) * cout_n + cout] : 0.0f;
+      }
+    }
+    for (int lane = 0; lane < 64; ++lane) {
+      const int cout = lane & 15;
+      packed[40 * 64 + lane] = ((lane >> 4) == 0 && cout < cout_n) ? b[cout] : 0.0f;
+    }
+    int rc = upload(packed, &m->d_w_final);
+    if (rc) return rc;
+    m->dp.w_final = m->d_w_final;
+  }
+  return DDD_OK;
+}
+
+void decide_mfma(ddd_model* m) {
+  const ddd::DevParams& dp = m->dp;
+  char why[256] = "";
+  bool ok = true;
+  auto no = [&](const char* msg) { if (ok) snprintf(why, sizeof(why), "%s", msg); ok = false; };
+  if (dp.N < 8 || dp.N > ddd::mfma::kRows) no("num_points outside [8, 256]");
+  if (dp.G > ddd::kGMax) no("stencil wider than 8");
+  if (!dp.fixed) {
+    if (dp.target != ddd::TARGET_COEFFICIENTS) no("model_target is not 'coefficients'");
+    if (dp.pao <= 0) no("polynomial_accuracy_order is 0");
+    if (dp.F != ddd::mfma::kF) no("filter_size != 32");
+    if (dp.K != ddd::mfma::kKW) no("kernel_size != 5");
+    if (dp.L < 2) no("fewer than 2 conv layers");
+    if (dp.C_out > 16) no("more than 16 output channels");
+  }
+  m->mfma_ok = ok;
+  m->mfma_reason = why;
+  m->kernel = ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;
+}
+
+int check_generic_lds(const ddd_model* m, int state_bytes) {
+  const size_t need = ddd::generic::lds_bytes(m->dp, state_bytes);
+  if (need > 160 * 1024)
+    return fail(DDD_ERR_UNSUPPORTED,
+                "generic kernel needs %zu B of LDS per sample (limit 163840): "
+                "num_points x channels too large", need);
+  return DDD_OK;
+}
+
+int ensure_scratch(ddd_model* m, size_t floats) {
+  if (m->scratch_floats >= floats) return DDD_OK;
+  free_dev(m->d_scratch);
+  m->d_scratch = nullptr;
+  m->scratch_floats = 0;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_scratch), floats * sizeof(float)));
+  m->scratch_floats = floats;
+  return DDD_OK;
+}
+
+int check_batch(const ddd_model* m, int batch) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (batch < 0) return fail(DDD_ERR_INVALID_ARGUMENT, "negative batch");
+  if (m->dp.forced && batch > m->dp.forcing_batch)
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "batch %d exceeds the %d samples forcing was set for", batch,
+                m->dp.forcing_batch);
+  return DDD_OK;
+}
+
+int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
+  if (a.batch == 0) return DDD_OK;
+  if (m->kernel == DDD_KERNEL_MFMA) {
+    const int spg = ddd::mfma::kRows / m->dp.N;
+    const int blocks = (a.batch + spg - 1) / spg;
+    hipLaunchKernelGGL(ddd::mfma::substep_kernel, dim3(blocks), dim3(256), 0, stream,
+                       m->dp, a);
+  } else {
+    int rc = check_generic_lds(m, 0);
+    if (rc) return rc;
+    const size_t lds = ddd::generic::lds_bytes(m->dp, 0);
+    DDD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ddd::generic::substep_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ddd::generic::substep_kernel, dim3(a.batch),
+                       dim3(ddd::generic::kThreads), lds, stream, m->dp, a);
+  }
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+template <typename ST>
+int launch_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
+  if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
+  if (m->kernel == DDD_KERNEL_MFMA) {
+    const int spg = ddd::mfma::kRows / m->dp.N;
+    const int blocks = (a.batch + spg - 1) / spg;
+    const bool hoist = !m->dp.fixed && m->dp.L == 3;
+    if (hoist)
+      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<ST, true>), dim3(blocks), dim3(256),
+                         0, stream, m->dp, a);
+    else
+      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<ST, false>), dim3(blocks), dim3(256),
+                         0, stream, m->dp, a);
+  } else {
+    int rc = check_generic_lds(m, (int)sizeof(ST));
+    if (rc) return rc;
+    const size_t lds = ddd::generic::lds_bytes(m->dp, (int)sizeof(ST));
+    DDD_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(ddd::generic::integrate_kernel<ST>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((ddd::generic::integrate_kernel<ST>), dim3(a.batch),
+                       dim3(ddd::generic::kThreads), lds, stream, m->dp, a);
+  }
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int check_integrate_args(const ddd_model* m, int n_steps, int save_every,
+                         const void* y0, const void* y_out, int batch) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (n_steps < 0) return fail(DDD_ERR_INVALID_ARGUMENT, "negative n_steps");
+  if (save_every < 1) return fail(DDD_ERR_INVALID_ARGUMENT, "save_every must be >= 1");
+  if (batch > 0 && n_steps > 0 && (y0 == nullptr || y_out == nullptr))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "y0 / y_out is NULL");
+  return DDD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ddd_abi_version(void) { return DDD_ABI_VERSION; }
+
+const char* ddd_last_error(void) { return g_error.c_str(); }
+
+int ddd_scheme_stages(int scheme) {
+  ddd::Tableau tab;
+  if (make_tableau(scheme, &tab) != DDD_OK) return -1;
+  return tab.stages;
+}
+
+int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weights,
+                     const float* nullspace, size_t n_nullspace, const float* bias,
+                     size_t n_bias, ddd_model** out) {
+  if (out == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int rc = common_config_checks(cfg);
+  if (rc) return rc;
+  if (cfg->num_layers < 1 || cfg->num_layers > DDD_MAX_LAYERS)
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "num_layers = %d out of range [1, %d] (fold num_layers = 0 models "
+                "into ddd_baseline_create)", cfg->num_layers, DDD_MAX_LAYERS);
+  if (cfg->filter_size < 1 || cfg->kernel_size < 1)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "filter_size / kernel_size must be >= 1");
+  if (cfg->activation < DDD_ACT_RELU || cfg->activation > DDD_ACT_ELU)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown activation %d", cfg->activation);
+  if (cfg->model_target < DDD_TARGET_COEFFICIENTS || cfg->model_target > DDD_TARGET_FLUX)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown model_target %d", cfg->model_target);
+  if (!(cfg->standard_deviation > 0.0))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "standard_deviation must be positive");
+  if (weights == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "weights is NULL");
+
+  ddd_model* m = new ddd_model();
+  m->cfg = *cfg;
+  fill_equation(*cfg, &m->dp);
+  ddd::DevParams& dp = m->dp;
+  dp.fixed = 0;
+  dp.target = cfg->model_target;
+  dp.L = cfg->num_layers;
+  dp.F = cfg->filter_size;
+  dp.K = cfg->kernel_size;
+  dp.act = cfg->activation;
+  dp.pao = cfg->polynomial_accuracy_order;
+  dp.unbiased = cfg->ensure_unbiased_coefficients;
+
+  const bool projected = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao > 0;
+  int c_out = 1;
+  if (dp.target == ddd::TARGET_COEFFICIENTS) {
+    if (projected) {
+      c_out = 0;
+      for (int d = 0; d < dp.D; ++d) {
+        if (cfg->input_sizes[d] < 1 || cfg->input_sizes[d] > dp.G) {
+          delete m;
+          return fail(DDD_ERR_INVALID_ARGUMENT, "input_sizes[%d] = %d out of range [1, G]",
+                      d, cfg->input_sizes[d]);
+        }
+        dp.in_start[d] = c_out;
+        dp.in_size[d] = cfg->input_sizes[d];
+        dp.ns_off[d] = c_out * dp.G;
+        c_out += cfg->input_sizes[d];
+      }
+    } else {
+      c_out = dp.D * dp.G;
+    }
+  } else if (dp.target == ddd::TARGET_SPACE_DERIVATIVES) {
+    c_out = dp.D;
+  }
+  dp.C_out = c_out;
+
+  size_t off = 0;
+  int64_t fma = 0;
+  for (int l = 0; l < dp.L; ++l) {
+    dp.cin[l] = l == 0 ? 1 : dp.F;
+    dp.cout[l] = l == dp.L - 1 ? c_out : dp.F;
+    dp.w_off[l] = (int)off;
+    off += (size_t)dp.K * dp.cin[l] * dp.cout[l];
+    dp.b_off[l] = (int)off;
+    off += (size_t)dp.cout[l];
+    fma += (int64_t)dp.K * dp.cin[l] * dp.cout[l];
+  }
+  if (n_weights != off) {
+    delete m;
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "n_weights = %zu, configuration needs %zu floats", n_weights, off);
+  }
+  if (dp.target == ddd::TARGET_COEFFICIENTS) {
+    if (projected) for (int d = 0; d < dp.D; ++d) fma += (int64_t)dp.in_size[d] * dp.G;
+    fma += (int64_t)dp.D * dp.G;
+  }
+  m->fma_per_point = fma;
+
+  if (projected) {
+    if (nullspace == nullptr || bias == nullptr || n_nullspace != (size_t)c_out * dp.G ||
+        n_bias != (size_t)dp.D * dp.G) {
+      delete m;
+      return fail(DDD_ERR_INVALID_ARGUMENT,
+                  "nullspace/bias required: expected %zu and %zu floats, got %zu and %zu",
+                  (size_t)c_out * dp.G, (size_t)dp.D * dp.G, n_nullspace, n_bias);
+    }
+  }
+
+  std::vector<float> wv(weights, weights + n_weights);
+  rc = upload(wv, &m->d_weights);
+  dp.weights = m->d_weights;
+  if (!rc && projected) {
+    std::vector<float> nv(nullspace, nullspace + n_nullspace);
+    std::vector<float> bv(bias, bias + n_bias);
+    rc = upload(nv, &m->d_nullspace);
+    if (!rc) rc = upload(bv, &m->d_bias);
+    dp.nullspace = m->d_nullspace;
+    dp.bias = m->d_bias;
+  }
+  if (!rc) {
+    decide_mfma(m);
+    if (m->mfma_ok) {
+      rc = upload_padded_tables(m, nullspace, bias);
+      if (!rc) rc = pack_mfma_weights(m, weights);
+    }
+  }
+  if (rc) { ddd_model_destroy(m); return rc; }
+  *out = m;
+  return DDD_OK;
+}
+
+int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_stencils,
+                        ddd_model** out) {
+  if (out == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int rc = common_config_checks(cfg);
+  if (rc) return rc;
+  if (stencils == nullptr ||
+      n_stencils != (size_t)cfg->num_derivatives * cfg->stencil_size)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "stencils must hold D*G = %d floats, got %zu",
+                cfg->num_derivatives * cfg->stencil_size, n_stencils);
+  ddd_model* m = new ddd_model();
+  m->cfg = *cfg;
+  fill_equation(*cfg, &m->dp);
+  m->dp.fixed = 1;
+  m->dp.stddev = 1.0f;
+  m->fma_per_point = (int64_t)cfg->num_derivatives * cfg->stencil_size;
+  std::vector<float> sv(stencils, stencils + n_stencils);
+  rc = upload(sv, &m->d_bias);
+  m->dp.bias = m->d_bias;
+  if (!rc) {
+    decide_mfma(m);
+    if (m->mfma_ok) rc = upload_padded_tables(m, nullptr, stencils);
+  }
+  if (rc) { ddd_model_destroy(m); return rc; }
+  *out = m;
+  return DDD_OK;
+}
+
+int ddd_model_destroy(ddd_model* m) {
+  if (m == nullptr) return DDD_OK;
+  free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
+  free_dev(m->d_nullspace8); free_dev(m->d_bias8); free_dev(m->d_w_hidden);
+  free_dev(m->d_w_input);
+  free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp);
+  free_dev(m->d_scratch);
+  delete m;
+  return DDD_OK;
+}
+
+int ddd_clear_forcing(ddd_model* m) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  free_dev(m->d_frc); free_dev(m->d_sp);
+  m->d_frc = nullptr; m->d_sp = nullptr;
+  m->dp.forced = 0; m->dp.P = 0; m->dp.n_k = 0; m->dp.forcing_batch = 0;
+  m->dp.frc = nullptr; m->dp.sp = nullptr;
+  return DDD_OK;
+}
+
+int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude,
+                    const float* omega, const float* phase, const int32_t* k_index,
+                    const float* spatial_phase, int n_k) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (batch < 1 || nparams < 1 || n_k < 1)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "batch, nparams and n_k must be >= 1");
+  if (!amplitude || !omega || !phase || !k_index || !spatial_phase)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "NULL forcing table");
+  int rc = ddd_clear_forcing(m);
+  if (rc) return rc;
+  if (!is_forced_family(m->cfg.equation)) return DDD_OK;   // finalize is the identity
+  const size_t count = (size_t)batch * nparams;
+  std::vector<float4> packed(count);
+  for (size_t i = 0; i < count; ++i) {
+    if (k_index[i] < 0 || k_index[i] >= n_k)
+      return fail(DDD_ERR_INVALID_ARGUMENT, "k_index[%zu] = %d outside [0, %d)", i,
+                  k_index[i], n_k);
+    float kbits;
+    const int32_t ki = k_index[i];
+    std::memcpy(&kbits, &ki, sizeof(kbits));
+    packed[i] = make_float4(amplitude[i], omega[i], phase[i], kbits);
+  }
+  std::vector<float> sp(spatial_phase, spatial_phase + (size_t)n_k * m->dp.N);
+  rc = upload(packed, &m->d_frc);
+  if (!rc) rc = upload(sp, &m->d_sp);
+  if (rc) return rc;
+  m->dp.frc = m->d_frc;
+  m->dp.sp = m->d_sp;
+  m->dp.forced = 1;
+  m->dp.P = nparams;
+  m->dp.n_k = n_k;
+  m->dp.forcing_batch = batch;
+  return DDD_OK;
+}
+
+int ddd_time_derivative(ddd_model* m, double t, const float* y, float* dydt, int batch,
+                        void* stream) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (batch > 0 && (!y || !dydt)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  ddd::SubstepArgs a{};
+  a.t = t; a.y_in = y; a.c1 = 1.0f; a.y_out = dydt; a.batch = batch;
+  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_rk_substep(ddd_model* m, double t, const float* y_in, const float* y_base,
+                   float c1, float* y_out, const float* acc_in, float c2,
+                   float* acc_out, int batch, void* stream) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (batch > 0 && !y_in) return fail(DDD_ERR_INVALID_ARGUMENT, "y_in is NULL");
+  if (batch > 0 && !y_out && !acc_out)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "both y_out and acc_out are NULL");
+  ddd::SubstepArgs a{};
+  a.t = t; a.y_in = y_in; a.y_base = y_base; a.c1 = c1; a.y_out = y_out;
+  a.acc_in = acc_in; a.c2 = c2; a.acc_out = acc_out; a.batch = batch;
+  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_space_derivatives(ddd_model* m, const float* y, float* out, int batch,
+                          void* stream) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (batch > 0 && (!y || !out)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (!m->dp.fixed && m->dp.target != ddd::TARGET_COEFFICIENTS &&
+      m->dp.target != ddd::TARGET_SPACE_DERIVATIVES)
+    return fail(DDD_ERR_UNSUPPORTED, "model_target has no spatial derivatives");
+  ddd::SubstepArgs a{};
+  a.y_in = y; a.derivs_out = out; a.batch = batch;
+  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_coefficients(ddd_model* m, const float* y, float* out, int batch, void* stream) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (batch > 0 && (!y || !out)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (!m->dp.fixed && m->dp.target != ddd::TARGET_COEFFICIENTS)
+    return fail(DDD_ERR_UNSUPPORTED, "model_target does not produce coefficients");
+  ddd::SubstepArgs a{};
+  a.y_in = y; a.coeffs_out = out; a.batch = batch;
+  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, double dt,
+                        int n_steps, int save_every, const float* y0, float* y_out,
+                        int batch, void* stream_) {
+  int rc = check_integrate_args(m, n_steps, save_every, y0, y_out, batch);
+  if (rc) return rc;
+  ddd::Tableau tab;
+  rc = make_tableau(scheme, &tab);
+  if (rc) return rc;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (launch_mode == DDD_LAUNCH_PERSISTENT) {
+    ddd::IntegrateArgs a{};
+    a.t0 = t0; a.dt = dt; a.n_steps = n_steps; a.save_every = save_every; a.tab = tab;
+    a.y0 = y0; a.y_out = y_out; a.batch = batch;
+    return launch_integrate<float>(m, a, stream);
+  }
+  if (launch_mode != DDD_LAUNCH_PER_SUBSTEP)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown launch_mode %d", launch_mode);
+  if (batch == 0 || n_steps == 0) return DDD_OK;
+
+  // One fused launch per substep; the state lives in HBM between launches.
+  const size_t elems = (size_t)batch * m->dp.N;
+  rc = ensure_scratch(m, 3 * elems);
+  if (rc) return rc;
+  float* ping = m->d_scratch;
+  float* pong = m->d_scratch + elems;
+  float* ystage = m->d_scratch + 2 * elems;
+  const float h = (float)dt;
+  const float* y = y0;
+  size_t snap = 0;
+  for (int step = 0; step < n_steps; ++step) {
+    const double t = t0 + (double)step * dt;
+    const bool saving = (step + 1) % save_every == 0;
+    float* ynew = saving ? y_out + snap * elems : (y == ping ? pong : ping);
+    const float* acc = nullptr;   // nullptr: accumulator still equals y
+    for (int s = 0; s < tab.stages; ++s) {
+      ddd::SubstepArgs a{};
+      a.t = t + tab.c[s] * dt;
+      a.y_in = s == 0 ? y : ystage;
+      a.batch = batch;
+      const bool last = s == tab.stages - 1;
+      if (!last) {   // next stage input  y + a_{s+1} h f
+        a.y_base = y; a.c1 = tab.a[s + 1] * h; a.y_out = ystage;
+      }
+      if (tab.b[s] != 0.0f || last) {
+        a.acc_in = acc != nullptr ? acc : y;
+        a.c2 = tab.b[s] * h;
+        a.acc_out = ynew;
+        acc = ynew;
+      }
+      rc = launch_substep(m, a, stream);
+      if (rc) return rc;
+    }
+    y = ynew;
+    if (saving) ++snap;
+  }
+  return DDD_OK;
+}
+
+int ddd_integrate_fixed_f64(ddd_model* m, int scheme, double t0, double dt, int n_steps,
+                            int save_every, const double* y0, double* y_out, int batch,
+                            void* stream) {
+  int rc = check_integrate_args(m, n_steps, save_every, y0, y_out, batch);
+  if (rc) return rc;
+  ddd::IntegrateArgs a{};
+  rc = make_tableau(scheme, &a.tab);
+  if (rc) return rc;
+  a.t0 = t0; a.dt = dt; a.n_steps = n_steps; a.save_every = save_every;
+  a.y0 = y0; a.y_out = y_out; a.batch = batch;
+  return launch_integrate<double>(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_conv1d_periodic(const float* in, const float* filters, const float* bias,
+                        float* out, int batch, int n, int cin, int cout, int k,
+                        int center, int activation, void* stream) {
+  if (!in || !filters || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (batch < 0 || n < 1 || cin < 1 || cout < 1 || k < 1)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "bad conv1d shape");
+  if (activation < -1 || activation > DDD_ACT_ELU)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown activation %d", activation);
+  const long total = (long)batch * n * cout;
+  if (total == 0) return DDD_OK;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(ddd::ops::conv1d_periodic_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, filters, bias, out, batch, n,
+                     cin, cout, k, center ? k / 2 : 0, activation);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c, int padding,
+                     int center, void* stream) {
+  if (!in || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (batch < 0 || n < 1 || c < 1 || padding < 0)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "bad pad_periodic shape");
+  const long total = (long)batch * (n + padding) * c;
+  if (total == 0) return DDD_OK;
+  const int left = center ? (padding + 1) / 2 : 0;   // layers.py:76-79
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(ddd::ops::pad_periodic_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, batch, n, c, padding, left);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
+                                  const float* bias, float* out, int64_t m,
+                                  int input_size, int g, void* stream) {
+  if (!inputs || !nullspace || !bias || !out)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (m < 0 || input_size < 1 || g < 1)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "bad polynomial_accuracy shape");
+  if (m == 0) return DDD_OK;
+  const long total = (long)m * g;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(ddd::ops::polynomial_accuracy_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), inputs, nullspace, bias, out,
+                     (long)m, input_size, g);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_set_kernel(ddd_model* m, int kind) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  switch (kind) {
+    case DDD_KERNEL_AUTO:
+      m->kernel = m->mfma_ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;
+      return DDD_OK;
+    case DDD_KERNEL_GENERIC:
+      m->kernel = DDD_KERNEL_GENERIC;
+      return DDD_OK;
+    case DDD_KERNEL_MFMA:
+      if (!m->mfma_ok)
+        return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
+                    m->mfma_reason.c_str());
+      m->kernel = DDD_KERNEL_MFMA;
+      return DDD_OK;
+    default:
+      return fail(DDD_ERR_INVALID_ARGUMENT, "unknown kernel kind %d", kind);
+  }
+}
+
+const char* ddd_kernel_name(const ddd_model* m) {
+  if (m == nullptr) return "";
+  return m->kernel == DDD_KERNEL_MFMA ? "mfma_f32" : "generic";
+}
+
+int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
+
+int ddd_selftest_mfma_layout(void) {
+  float* d32 = nullptr;
+  float* d16 = nullptr;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d32), 32 * 32 * sizeof(float)));
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d16), 16 * 16 * sizeof(float)));
+  hipLaunchKernelGGL(ddd::ops::mfma_layout_probe_kernel, dim3(1), dim3(64), 0, nullptr,
+                     d32, d16);
+  DDD_HIP(hipGetLastError());
+  std::vector<float> h32(32 * 32), h16(16 * 16);
+  DDD_HIP(hipMemcpy(h32.data(), d32, h32.size() * sizeof(float), hipMemcpyDeviceToHost));
+  DDD_HIP(hipMemcpy(h16.data(), d16, h16.size() * sizeof(float), hipMemcpyDeviceToHost));
+  (void)hipFree(d32);
+  (void)hipFree(d16);
+  for (int i = 0; i < 32; ++i)
+    for (int j = 0; j < 32; ++j) {
+      const float want = (float)(i + 1) * (float)(64 * (j + 1)) +
+                         (float)(1000 + i) * (float)(3 * j + 7);
+      if (h32[i * 32 + j] != want)
+        return fail(DDD_ERR_UNSUPPORTED,
+                    "mfma_f32_32x32x2 layout mismatch at D[%d][%d]: got %g want %g", i, j,
+                    h32[i * 32 + j], want);
+    }
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j) {
+      float want = 0.0f;
+      for (int k = 0; k < 4; ++k)
+        want = fmaf((float)((k + 1) * 100 + i), (float)((k + 2) * (j + 1)), want);
+      if (h16[i * 16 + j] != want)
+        return fail(DDD_ERR_UNSUPPORTED,
+                    "mfma_f32_16x16x4 layout mismatch at D[%d][%d]: got %g want %g", i, j,
+                    h16[i * 16 + j], want);
+    }
+  return DDD_OK;
+}
+
+}  // extern "C"

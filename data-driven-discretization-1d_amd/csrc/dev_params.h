@@ -1,0 +1,134 @@
+// Device-side parameter blocks shared by the kernels and the C-ABI layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ddd {
+
+constexpr int kMaxDerivs = 4;
+constexpr int kMaxLayers = 8;
+constexpr int kMaxStages = 4;
+constexpr int kGMax = 8;      // widest stencil the MFMA path handles
+constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
+
+// Equation ids: include/ddd1d.h enum ddd_equation.
+enum : int {
+  EQ_BURGERS = 0, EQ_BURGERS_CONS = 1, EQ_KDV = 2, EQ_KDV_CONS = 3,
+  EQ_KS = 4, EQ_KS_CONS = 5, EQ_BURGERS_GODUNOV = 6, EQ_KDV_GODUNOV = 7,
+  EQ_KS_GODUNOV = 8
+};
+enum : int { ACT_NONE = -1, ACT_RELU = 0, ACT_RELU6 = 1, ACT_TANH = 2,
+             ACT_SOFTPLUS = 3, ACT_ELU = 4 };
+enum : int { TARGET_COEFFICIENTS = 0, TARGET_SPACE_DERIVATIVES = 1,
+             TARGET_TIME_DERIVATIVE = 2, TARGET_FLUX = 3 };
+
+struct DevParams {
+  // equation + grid
+  int equation, N, D, G;
+  float eta, stddev, inv_dx;
+  int conservative;    // flux form: needs the staggered difference
+  // model
+  int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
+  int target, L, F, K, act, C_out, pao, unbiased;
+  int in_start[kMaxDerivs], in_size[kMaxDerivs], ns_off[kMaxDerivs];
+  int w_off[kMaxLayers], b_off[kMaxLayers], cin[kMaxLayers], cout[kMaxLayers];
+  const float* weights;    // natural layout, layer-major (kernel then bias)
+  const float* nullspace;  // per derivative [in_size][G]
+  const float* bias;       // [D][G]  (accuracy-layer bias, or fixed stencils)
+  const float* nullspace8; // same, rows zero-padded to 8 columns (MFMA path)
+  const float* bias8;      // [D][8]
+  int ns8_off[kMaxDerivs];
+  const float* w_input;    // MFMA-packed input layer, 3 x 64
+  const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
+  const float* w_final;    // MFMA-packed output layer, 41 x 64
+  // per-sample forcing
+  int forced, P, n_k, forcing_batch;
+  const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)
+  const float* sp;         // [n_k][N]   spatial phase table
+};
+
+// Explicit RK tableau in "previous-stage only" form:
+//   u_s = y + a[s] * h * k_{s-1},  t_s = t + c[s] * h,  y' = y + sum b[s] h k_s
+struct Tableau {
+  int stages;
+  float a[kMaxStages];
+  float b[kMaxStages];
+  double c[kMaxStages];
+};
+
+struct IntegrateArgs {
+  double t0, dt;
+  int n_steps, save_every;
+  Tableau tab;
+  const void* y0;   // [batch][N] StateT
+  void* y_out;      // [n_saved][batch][N] StateT
+  int batch;
+};
+
+struct SubstepArgs {
+  double t;
+  const float* y_in;
+  const float* y_base;   // may be null
+  float c1;
+  float* y_out;          // may be null
+  const float* acc_in;   // may be null
+  float c2;
+  float* acc_out;        // may be null
+  float* derivs_out;     // [batch][N][D] or null
+  float* coeffs_out;     // [batch][N][D][G] or null
+  int batch;
+};
+
+__device__ __forceinline__ float apply_activation(float x, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(x, 0.0f);
+    case ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
+    case ACT_TANH: return tanhf(x);
+    case ACT_SOFTPLUS: return (x > 0.0f ? x : 0.0f) + log1pf(expf(-fabsf(x)));
+    case ACT_ELU: return x > 0.0f ? x : expm1f(x);
+    default: return x;
+  }
+}
+
+// Godunov flux for u^2/2 (equations.py:341-349).
+__device__ __forceinline__ float godunov_flux(float um, float up) {
+  const float a = um * um, b = up * up;
+  return 0.5f * (um <= up ? fminf(a, b) : fmaxf(a, b));
+}
+
+// u_t for the non-flux forms, or the flux for the flux forms.  `d` holds the
+// spatial derivatives in DERIVATIVE_NAMES order.  Arithmetic mirrors the
+// expression order of the reference's equation_of_motion methods.
+__device__ __forceinline__ float equation_rhs_or_flux(int eq, float y,
+                                                      const float (&d)[kMaxDerivs],
+                                                      float eta) {
+  switch (eq) {
+    case EQ_BURGERS: return eta * d[1] - y * d[0];
+    case EQ_BURGERS_CONS: return 0.5f * (d[0] * d[0]) - eta * d[1];
+    case EQ_BURGERS_GODUNOV: return godunov_flux(d[0], d[1]) - eta * d[2];
+    case EQ_KDV: return (-6.0f * y) * d[0] - d[1];
+    case EQ_KDV_CONS: return 3.0f * (d[0] * d[0]) + d[1];
+    case EQ_KDV_GODUNOV: return 6.0f * godunov_flux(d[0], d[1]) + d[2];
+    case EQ_KS: return (-y * d[0] - d[2]) - d[1];
+    case EQ_KS_CONS: return (0.5f * (d[0] * d[0]) + d[2]) + d[1];
+    case EQ_KS_GODUNOV: return (d[3] + d[2]) + godunov_flux(d[0], d[1]);
+    default: return 0.0f;
+  }
+}
+
+// Forcing of one sample at one grid point: sum_j a sin((omega t + sp) + phi),
+// float32 in the TF graph's order (equations.py:214-219).
+__device__ __forceinline__ float forcing_at(const DevParams& p, const float4* frc,
+                                            int pos, float t) {
+  float total = 0.0f;
+  for (int m = 0; m < p.P; ++m) {
+    const float4 q = frc[m];
+    const int kidx = __float_as_int(q.w);
+    const float sp = p.sp[kidx * p.N + pos];
+    const float phase = __fadd_rn(__fadd_rn(__fmul_rn(q.y, t), sp), q.z);
+    total = __fadd_rn(total, __fmul_rn(q.x, sinf(phase)));
+  }
+  return total;
+}
+
+}  // namespace ddd

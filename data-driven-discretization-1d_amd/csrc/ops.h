@@ -1,0 +1,117 @@
+// Standalone operators: the reference's unit-test surface for this path
+// (layers_test.py, polynomials_test.py) plus the MFMA register-layout probe.
+#pragma once
+#include "dev_params.h"
+
+namespace ddd {
+namespace ops {
+
+// layers.nn_conv1d_periodic / conv1d_periodic_layer (layers.py:95-137):
+// out[b,x,f] = bias[f] + sum_{k,c} in[b, (x + k - left) mod N, c] * w[k,c,f],
+// left = ceil((K-1)/2) when centred, 0 otherwise (layers.py:76-83).
+__global__ void conv1d_periodic_kernel(const float* __restrict__ in,
+                                       const float* __restrict__ w,
+                                       const float* __restrict__ bias,
+                                       float* __restrict__ out, int batch, int n,
+                                       int cin, int cout, int k, int left, int act) {
+  const long total = (long)batch * n * cout;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % cout);
+    const long bx = idx / cout;
+    const int x = (int)(bx % n);
+    const long b = bx / n;
+    float acc = 0.0f;
+    for (int kk = 0; kk < k; ++kk) {
+      int src = (x + kk - left) % n;
+      src = src < 0 ? src + n : src;
+      const float* row = in + ((size_t)b * n + src) * cin;
+      const float* wk = w + (size_t)kk * cin * cout + co;
+      for (int ci = 0; ci < cin; ++ci) acc = fmaf(row[ci], wk[(size_t)ci * cout], acc);
+    }
+    if (bias != nullptr) acc = acc + bias[co];
+    out[idx] = apply_activation(acc, act);
+  }
+}
+
+// layers.pad_periodic (layers.py:39-83): [B][N][C] -> [B][N+padding][C].
+__global__ void pad_periodic_kernel(const float* __restrict__ in,
+                                    float* __restrict__ out, int batch, int n,
+                                    int c, int padding, int left) {
+  const int np = n + padding;
+  const long total = (long)batch * np * c;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int ch = (int)(idx % c);
+    const long bx = idx / c;
+    const int x = (int)(bx % np);
+    const long b = bx / np;
+    int src = (x - left) % n;
+    src = src < 0 ? src + n : src;
+    out[idx] = in[((size_t)b * n + src) * c + ch];
+  }
+}
+
+// PolynomialAccuracyLayer.apply (polynomials.py:266-277):
+// out[m][g] = bias[g] + sum_i in[m][i] * nullspace[i][g].
+__global__ void polynomial_accuracy_kernel(const float* __restrict__ in,
+                                           const float* __restrict__ nullspace,
+                                           const float* __restrict__ bias,
+                                           float* __restrict__ out, long m,
+                                           int input_size, int g) {
+  const long total = m * g;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int gg = (int)(idx % g);
+    const long row = idx / g;
+    float acc = 0.0f;
+    for (int i = 0; i < input_size; ++i)
+      acc = fmaf(in[row * input_size + i], nullspace[i * g + gg], acc);
+    out[idx] = bias[gg] + acc;
+  }
+}
+
+// MFMA layout probe: D = A * B with A[i][k] = 1 + i + 100 k (distinct per
+// element) and B[k][j] = (k == 0) ? (j == j0) : 0 style one-hot products are
+// overkill; instead feed integer-valued matrices whose product identifies
+// every (i, j) uniquely and compare against the layout the kernels assume.
+//   32x32x2: A[i][k] = (k == 0) ? i + 1 : 0,  B[k][j] = (k == 0) ? 64 (j + 1) : 0
+//            => D[i][j] = 64 (i + 1)(j + 1)  (asymmetric in i <-> j via the 64)
+//   plus a second product exercising k == 1 so that a k-swap is caught.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void mfma_layout_probe_kernel(float* __restrict__ out32,
+                                         float* __restrict__ out16) {
+  const int l = threadIdx.x;
+  {
+    // A[i][k]: lane l supplies i = l & 31, k = l >> 5.
+    const int i = l & 31, k = l >> 5;
+    const float a = (k == 0) ? (float)(i + 1) : (float)(1000 + i);
+    // B[k][j]: lane l supplies k = l >> 5, j = l & 31.
+    const int j = l & 31;
+    const float b = (k == 0) ? (float)(64 * (j + 1)) : (float)(3 * j + 7);
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    // Store by the ASSUMED layout: register r of lane l is
+    // D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      out32[row * 32 + (l & 31)] = acc[r];
+    }
+  }
+  {
+    const int i = l & 15, k = l >> 4;
+    const float a = (float)((k + 1) * 100 + i);
+    const int j = l & 15;
+    const float b = (float)((k + 2) * (j + 1));
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    // ASSUMED: register r of lane l is D[4 (l >> 4) + r][l & 15].
+    for (int r = 0; r < 4; ++r) out16[(4 * (l >> 4) + r) * 16 + (l & 15)] = acc[r];
+  }
+}
+
+}  // namespace ops
+}  // namespace ddd

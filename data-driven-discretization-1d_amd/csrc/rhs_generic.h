@@ -1,0 +1,232 @@
+// Generic (any configuration) learned-stencil right-hand side on the VALU.
+//
+// One workgroup per sample, activations ping-pong through dynamic LDS
+// [N][Cmax] float32, every (grid point, output channel) pair is one fmaf
+// chain.  Handles what the MFMA path does not: arbitrary N, kernel size,
+// filter size, layer count, activation, stencil width, the accuracy-order-0
+// head, and the space_derivatives / time_derivative / flux model targets
+// (model.py:551-615).  It is an order of magnitude slower than the MFMA path
+// and exists for coverage, not for speed.
+#pragma once
+#include "dev_params.h"
+
+namespace ddd {
+namespace generic {
+
+constexpr int kThreads = 256;
+
+struct Carve {
+  float* act_a;
+  float* act_b;
+  float* u;      // [N]
+  float* flux;   // [N]
+  float* dy;     // [N]
+};
+
+__host__ __device__ inline int max_channels(const DevParams& p) {
+  int c = 1;
+  for (int l = 0; l < p.L; ++l) c = p.cout[l] > c ? p.cout[l] : c;
+  return c;
+}
+
+// Bytes of dynamic LDS for `state_bytes`-wide integration state (0 for the
+// substep kernel).
+__host__ __device__ inline size_t lds_bytes(const DevParams& p, int state_bytes) {
+  const size_t n = (size_t)p.N;
+  size_t floats = 3 * n;
+  if (!p.fixed) floats += 2 * n * (size_t)max_channels(p);
+  size_t bytes = floats * sizeof(float);
+  bytes = (bytes + 15) & ~(size_t)15;
+  if (state_bytes) bytes += 2 * n * (size_t)state_bytes + n * sizeof(float);
+  return bytes;
+}
+
+__device__ __forceinline__ Carve carve(const DevParams& p, float* base) {
+  Carve c;
+  const int cm = p.fixed ? 0 : max_channels(p);
+  c.act_a = base;
+  c.act_b = base + (size_t)p.N * cm;
+  c.u = base + 2 * (size_t)p.N * cm;
+  c.flux = c.u + p.N;
+  c.dy = c.flux + p.N;
+  return c;
+}
+
+__device__ __forceinline__ int wrap(int i, int n) {
+  i %= n;
+  return i < 0 ? i + n : i;
+}
+
+// dy[0..N) = finalize_time_derivative(t, predict_time_derivative(u[0..N)))
+// for the sample this workgroup owns.  u and dy live in LDS (c.u, c.dy).
+__device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
+                                float t, float* derivs_out, float* coeffs_out) {
+  const int tid = threadIdx.x;
+  const int n = p.N;
+  const float* net = nullptr;   // [N][C_out]
+  if (!p.fixed) {
+    for (int i = tid; i < n; i += kThreads) c.act_a[i] = c.u[i] / p.stddev;
+    __syncthreads();
+    float* cur = c.act_a;
+    float* nxt = c.act_b;
+    for (int l = 0; l < p.L; ++l) {
+      const int cin = p.cin[l], cout = p.cout[l];
+      const float* __restrict__ w = p.weights + p.w_off[l];
+      const float* __restrict__ b = p.weights + p.b_off[l];
+      const int act = (l < p.L - 1) ? p.act : ACT_NONE;
+      const int left = p.K / 2;   // ceil((K-1)/2): layers.pad_periodic(center=True)
+      for (int idx = tid; idx < n * cout; idx += kThreads) {
+        const int pos = idx / cout;
+        const int co = idx - pos * cout;
+        float acc = 0.0f;
+        for (int k = 0; k < p.K; ++k) {
+          const float* __restrict__ row = cur + (size_t)wrap(pos + k - left, n) * cin;
+          const float* __restrict__ wk = w + (size_t)k * cin * cout + co;
+          for (int ci = 0; ci < cin; ++ci) acc = fmaf(row[ci], wk[(size_t)ci * cout], acc);
+        }
+        nxt[idx] = apply_activation(acc + b[co], act);
+      }
+      __syncthreads();
+      float* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    net = cur;
+  }
+
+  const int gl = p.G / 2;
+  const bool needs_flux_diff = p.conservative || p.target == TARGET_FLUX;
+  for (int pos = tid; pos < n; pos += kThreads) {
+    const float y = c.u[pos];
+    float r;
+    if (!p.fixed && p.target == TARGET_TIME_DERIVATIVE) {
+      r = net[pos];
+    } else if (!p.fixed && p.target == TARGET_FLUX) {
+      r = net[pos];
+    } else {
+      float dv[kMaxDerivs] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int d = 0; d < kMaxDerivs; ++d) {
+        if (d >= p.D) continue;
+        float s = 0.0f;
+        if (!p.fixed && p.target == TARGET_SPACE_DERIVATIVES) {
+          s = net[(size_t)pos * p.C_out + d];
+        } else {
+          float mean = 0.0f;
+          if (!p.fixed && p.pao == 0 && p.unbiased) {
+            for (int g = 0; g < p.G; ++g) mean += net[(size_t)pos * p.C_out + d * p.G + g];
+            mean = mean / (float)p.G;
+          }
+          for (int g = 0; g < p.G; ++g) {
+            float coeff;
+            if (p.fixed) {
+              coeff = p.bias[d * p.G + g];
+            } else if (p.pao == 0) {
+              coeff = net[(size_t)pos * p.C_out + d * p.G + g] - mean;
+            } else {
+              const float* __restrict__ ns = p.nullspace + p.ns_off[d];
+              const float* __restrict__ nv = net + (size_t)pos * p.C_out + p.in_start[d];
+              float proj = 0.0f;
+              for (int jx = 0; jx < p.in_size[d]; ++jx) proj = fmaf(nv[jx], ns[jx * p.G + g], proj);
+              coeff = p.bias[d * p.G + g] + proj;
+            }
+            if (coeffs_out != nullptr)
+              coeffs_out[(((size_t)sample * n + pos) * p.D + d) * p.G + g] = coeff;
+            s = fmaf(coeff, c.u[wrap(pos + g - gl, n)], s);
+          }
+        }
+        dv[d] = s;
+        if (derivs_out != nullptr)
+          derivs_out[((size_t)sample * n + pos) * p.D + d] = s;
+      }
+      r = equation_rhs_or_flux(p.equation, y, dv, p.eta);
+    }
+    if (needs_flux_diff) c.flux[pos] = r; else c.dy[pos] = r;
+  }
+  __syncthreads();
+  for (int pos = tid; pos < n; pos += kThreads) {
+    float r;
+    if (needs_flux_diff) {
+      const float here = c.flux[pos];
+      const float next = c.flux[pos + 1 == n ? 0 : pos + 1];
+      const float diff = p.inv_dx * (next - here);
+      // model.predict_flux_directly returns +staggered_first_derivative(flux)
+      // (model.py:609-615); the flux-form equations return its negative.
+      r = (!p.fixed && p.target == TARGET_FLUX) ? diff : -diff;
+    } else {
+      r = c.dy[pos];
+    }
+    if (p.forced) r = r + forcing_at(p, p.frc + (size_t)sample * p.P, pos, t);
+    c.dy[pos] = r;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kThreads) void substep_kernel(DevParams p, SubstepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Carve c = carve(p, smem);
+  const long sample = blockIdx.x;
+  const size_t off = (size_t)sample * p.N;
+  for (int i = threadIdx.x; i < p.N; i += kThreads) c.u[i] = a.y_in[off + i];
+  __syncthreads();
+  eval_rhs(p, c, sample, (float)a.t, a.derivs_out, a.coeffs_out);
+  for (int i = threadIdx.x; i < p.N; i += kThreads) {
+    const float f = c.dy[i];
+    if (a.y_out != nullptr) {
+      const float cf = a.c1 * f;
+      a.y_out[off + i] = a.y_base != nullptr ? a.y_base[off + i] + cf : cf;
+    }
+    if (a.acc_out != nullptr) {
+      const float cf = a.c2 * f;
+      a.acc_out[off + i] = a.acc_in != nullptr ? a.acc_in[off + i] + cf : cf;
+    }
+  }
+}
+
+template <typename ST>
+__global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, IntegrateArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const Carve c = carve(p, smem);
+  const size_t front = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  ST* y = reinterpret_cast<ST*>(reinterpret_cast<char*>(smem) + front);
+  ST* ynew = y + p.N;
+  float* kprev = reinterpret_cast<float*>(ynew + p.N);
+  const long sample = blockIdx.x;
+  const size_t off = (size_t)sample * p.N;
+  const ST* y0 = static_cast<const ST*>(a.y0);
+  ST* y_out = static_cast<ST*>(a.y_out);
+  for (int i = threadIdx.x; i < p.N; i += kThreads) y[i] = y0[off + i];
+  __syncthreads();
+  const ST h = (ST)a.dt;
+  const size_t snap_stride = (size_t)a.batch * p.N;
+  size_t snap = 0;
+  int until_save = a.save_every;
+  for (int step = 0; step < a.n_steps; ++step) {
+    const double t = a.t0 + (double)step * a.dt;
+    for (int s = 0; s < a.tab.stages; ++s) {
+      for (int i = threadIdx.x; i < p.N; i += kThreads) {
+        ST us = y[i];
+        if (s == 0) ynew[i] = us;
+        else us = us + (ST)kprev[i] * ((ST)a.tab.a[s] * h);
+        c.u[i] = (float)us;
+      }
+      __syncthreads();
+      eval_rhs(p, c, sample, (float)(t + a.tab.c[s] * a.dt), nullptr, nullptr);
+      for (int i = threadIdx.x; i < p.N; i += kThreads) {
+        const float f = c.dy[i];
+        if (a.tab.b[s] != 0.0f) ynew[i] = ynew[i] + ((ST)a.tab.b[s] * h) * (ST)f;
+        kprev[i] = f;
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < p.N; i += kThreads) y[i] = ynew[i];
+    if (--until_save == 0) {
+      until_save = a.save_every;
+      for (int i = threadIdx.x; i < p.N; i += kThreads)
+        y_out[snap * snap_stride + off + i] = ynew[i];
+      ++snap;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace generic
+}  // namespace ddd

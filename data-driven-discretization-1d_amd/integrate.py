@@ -1,0 +1,241 @@
+"""Time integration drivers with the reference's API, backed by HIP kernels.
+
+Mirror of ``pde_superresolution/integrate.py`` for the learned-stencil path:
+
+  Differentiator                 integrate.py:40-45
+  SavedModelDifferentiator       integrate.py:48-71   (HIP model instead of a TF session)
+  PolynomialDifferentiator       integrate.py:74-105
+  odeint                         integrate.py:143-169 (SciPy RK23, max_step 0.01)
+  integrate                      integrate.py:238-279
+  integrate_baseline             integrate.py:296-308
+  integrate_model_from_warm_start integrate.py:399-427
+
+plus ``integrate_batch``: the whole batch of independent initial conditions
+advanced on the GPU with a fixed step -- what ``scripts/run_evaluation.py``'s
+per-sample loop (run_evaluation.py:152-174) becomes on one MI355X.
+
+Results are ``xarray.Dataset`` objects when xarray is importable, otherwise a
+``Dataset`` stand-in exposing the same ``data_vars`` / ``coords`` mapping.
+"""
+import logging
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from . import equations as equations_lib
+from . import hparams as hparams_lib
+from . import model as model_lib
+
+_DEFAULT_TIMES = np.linspace(0, 10, num=201)
+
+try:  # pragma: no cover - xarray is optional
+  import xarray
+  _HAVE_XARRAY = True
+except ImportError:  # pragma: no cover
+  xarray = None
+  _HAVE_XARRAY = False
+
+
+class Dataset(dict):
+  """Minimal stand-in for xarray.Dataset: ds['y'] -> ndarray, ds.coords[...]."""
+
+  def __init__(self, data_vars, coords):
+    super(Dataset, self).__init__()
+    self.dims = {}
+    for name, (dims, values) in data_vars.items():
+      values = np.asarray(values)
+      self[name] = values
+      self.dims.update(dict(zip(dims, values.shape)))
+    self.data_vars = {k: v for k, v in self.items()}
+    self.coords = dict(coords)
+
+
+def _make_dataset(data_vars, coords):
+  if _HAVE_XARRAY:
+    return xarray.Dataset(data_vars=data_vars, coords=coords)
+  return Dataset(data_vars, coords)
+
+
+class Differentiator(object):
+  """Base class: ``__call__(t, y[x]) -> dy/dt[x]``."""
+
+  def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
+    raise NotImplementedError
+
+
+class _HipDifferentiator(Differentiator):
+  """One sample at a time through the batched kernel (batch = 1).
+
+  Like the reference's TF differentiators the input is cast to float32, the
+  derivative is computed on the device and returned to the host (here as
+  float32 NumPy, which SciPy promotes to float64).
+  """
+
+  def __init__(self, device_model):
+    self.model = device_model
+    self._torch = _lib.require_gpu()
+
+  def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
+    y32 = np.ascontiguousarray(np.asarray(y, dtype=np.float32)[np.newaxis, :])
+    out = self.model.time_derivative(y32, t)
+    return out[0].cpu().numpy()
+
+
+class SavedModelDifferentiator(_HipDifferentiator):
+  """Derivatives from a saved learned-stencil model (integrate.py:48-71).
+
+  ``checkpoint_dir`` holds ``hparams.json`` + ``model.npz`` written by
+  ``LearnedStencilModel.save``; alternatively pass an in-memory ``model``.
+  The equation's own RandomForcing is applied in finalize_time_derivative,
+  exactly as the reference does for the Burgers family.
+  """
+
+  def __init__(self, checkpoint_dir: Optional[str], equation, hparams=None,
+               model: Optional[model_lib.LearnedStencilModel] = None):
+    if model is None:
+      model = model_lib.LearnedStencilModel.load(checkpoint_dir, equation,
+                                                 hparams)
+    elif model.equation is not equation:
+      model = model_lib.LearnedStencilModel(
+          equation, model.hparams, model.conv_kernels, model.conv_biases,
+          model.nullspaces, model.biases, model.constant_coefficients)
+    if equation.has_time_dependent_forcing:
+      model.set_forcing_from_equation(batch=1)
+    super(SavedModelDifferentiator, self).__init__(model)
+
+
+class PolynomialDifferentiator(_HipDifferentiator):
+  """Standard finite difference / volume stencils (integrate.py:74-105)."""
+
+  def __init__(self, equation, accuracy_order: Optional[int] = 1):
+    model = model_lib.BaselineModel(equation, accuracy_order)
+    if equation.has_time_dependent_forcing:
+      model.set_forcing_from_equation(batch=1)
+    super(PolynomialDifferentiator, self).__init__(model)
+    self.equation = equation
+
+  def calculate_space_derivatives(self, y):
+    y32 = np.ascontiguousarray(np.asarray(y, dtype=np.float32)[np.newaxis, :])
+    derivs = self.model.space_derivatives(y32)[0].cpu().numpy()
+    return {name: derivs[:, i]
+            for i, name in enumerate(self.equation.DERIVATIVE_NAMES)}
+
+
+def odeint(y0: np.ndarray, differentiator: Differentiator, times: np.ndarray,
+           method: str = 'RK23') -> Tuple[np.ndarray, int]:
+  """integrate.py:143-169: SciPy solve_ivp, max_step 0.01, NaN-pad on failure."""
+  import scipy.integrate
+  logging.info('solve_ivp from %s to %s', times[0], times[-1])
+  sol = scipy.integrate.solve_ivp(differentiator, (times[0], times[-1]), y0,
+                                  t_eval=times, max_step=0.01, method=method)
+  y = sol.y.T   # (time, x)
+  logging.info('nfev: %r, njev: %r, nlu: %r', sol.nfev, sol.njev, sol.nlu)
+  logging.info('status: %r, message: %s', sol.status, sol.message)
+  num_missing = len(times) - y.shape[0]
+  if num_missing:
+    logging.info('padding with %s values', num_missing)
+    y = np.pad(y, ((0, num_missing), (0, 0)), mode='constant',
+               constant_values=np.nan)
+  return y, sol.nfev
+
+
+def integrate(equation, differentiator: Differentiator,
+              times: np.ndarray = _DEFAULT_TIMES, warmup: float = 0,
+              integrate_method: str = 'RK23', filter_interval: float = None,
+              filter_all_times: bool = False):
+  """integrate.py:238-279.
+
+  ``warmup`` / ``filter_interval`` need the fine-grid "exact" solvers (WENO /
+  spectral, integrate.py:108-140, 172-235), which are outside this path
+  (DESIGN.md "Out of scope"); they raise instead of silently differing.
+  """
+  if filter_interval is not None or filter_all_times:
+    raise NotImplementedError('periodic spectral filtering belongs to the '
+                              'exact solvers, outside the learned-stencil path')
+  if warmup:
+    raise NotImplementedError(
+        'warmup integrates the fine-grid exact equation (WENO / spectral); '
+        'provide y0 through integrate_model_from_warm_start instead')
+  y0 = equation.initial_value()
+  solution, num_evals = odeint(y0, differentiator, times=warmup + times,
+                               method=integrate_method)
+  return _make_dataset(
+      data_vars={'y': (('time', 'x'), solution)},
+      coords={'time': warmup + times, 'x': equation.grid.solution_x,
+              'num_evals': num_evals})
+
+
+def integrate_baseline(equation, times: np.ndarray = _DEFAULT_TIMES,
+                       warmup: float = 0, accuracy_order: int = 1,
+                       integrate_method: str = 'RK23',
+                       exact_filter_interval: float = None):
+  """integrate.py:296-308."""
+  differentiator = PolynomialDifferentiator(equation, accuracy_order)
+  return integrate(equation, differentiator, times, warmup,
+                   integrate_method=integrate_method,
+                   filter_interval=exact_filter_interval)
+
+
+def integrate_model_from_warm_start(checkpoint_dir: Optional[str],
+                                    y0: np.ndarray, hparams=None,
+                                    random_seed: int = 0,
+                                    times: np.ndarray = _DEFAULT_TIMES,
+                                    warmup: float = 0,
+                                    integrate_method: str = 'RK23',
+                                    model=None):
+  """integrate.py:399-427."""
+  if hparams is None:
+    hparams = (model.hparams if model is not None
+               else hparams_lib.load_hparams(checkpoint_dir))
+  _, equation_coarse = equations_lib.from_hparams(hparams,
+                                                  random_seed=random_seed)
+  differentiator = SavedModelDifferentiator(checkpoint_dir, equation_coarse,
+                                            hparams, model=model)
+  solution, num_evals = odeint(y0, differentiator, warmup + times,
+                               method=integrate_method)
+  return _make_dataset(
+      data_vars={'y': (('time', 'x'), solution)},
+      coords={'time': warmup + times, 'x': equation_coarse.grid.solution_x,
+              'num_evals': num_evals})
+
+
+def integrate_batch(device_model, y0, times: np.ndarray, dt: float = 0.01,
+                    scheme: str = 'bs3', forcing: Optional[dict] = None,
+                    launch_mode: str = 'persistent',
+                    state_dtype: str = 'float32'):
+  """All samples at once on the GPU with a fixed step.
+
+  ``times`` must be uniformly spaced multiples of ``dt`` starting at times[0];
+  sample b starts from y0[b].  With scheme='bs3' and dt = 0.01 this is what
+  the reference's solve_ivp(RK23, max_step=0.01) computes whenever its step
+  controller sits at max_step (the regime of notebooks/time-integration.ipynb).
+  Returns a Dataset with y [sample, time, x] and num_evals.
+  """
+  times = np.asarray(times, dtype=np.float64)
+  spacing = np.diff(times)
+  if len(times) < 2 or not np.allclose(spacing, spacing[0]):
+    raise ValueError('times must be uniformly spaced')
+  save_every = int(round(spacing[0] / dt))
+  if save_every < 1 or abs(save_every * dt - spacing[0]) > 1e-9 * max(1, spacing[0]):
+    raise ValueError('output spacing {} is not a multiple of dt {}'
+                     .format(spacing[0], dt))
+  if forcing is not None:
+    device_model.set_forcing(forcing)
+  num_steps = save_every * (len(times) - 1)
+  traj = device_model.integrate_fixed(
+      y0, num_steps, dt=dt, t0=float(times[0]), scheme=scheme,
+      save_every=save_every, launch_mode=launch_mode, state_dtype=state_dtype)
+  y0_dev = _lib.as_device(y0, traj.dtype)
+  full = _lib._torch().cat([y0_dev[None], traj], dim=0)   # [time, sample, x]
+  lib = _lib.load_library()
+  stages = lib.ddd_scheme_stages(_lib.SCHEMES[scheme])
+  y = full.permute(1, 0, 2).contiguous().cpu().numpy()
+  if np.isnan(y).any():
+    # divergence is reported as NaN rows, not an exception (integrate.py:161-167)
+    logging.info('some trajectories diverged (NaN rows)')
+  return _make_dataset(
+      data_vars={'y': (('sample', 'time', 'x'), y)},
+      coords={'time': times, 'x': device_model.equation.grid.solution_x,
+              'sample': np.arange(y.shape[0]),
+              'num_evals': stages * num_steps})

@@ -1,0 +1,276 @@
+/*
+ * ddd1d.h -- C ABI of libddd1d.so, the MI355X (gfx950) implementation of the
+ * per-timestep learned-stencil integration path of
+ * google/data-driven-discretization-1d (package pde_superresolution).
+ *
+ * The reference has no FFI: its plug-in seam for this path is the Python
+ * callable `Differentiator.__call__(t, y) -> dy/dt` (integrate.py:40-45)
+ * consumed by `integrate.odeint` (integrate.py:143-169), plus the batched
+ * fixed-step `model.integrate_ode` (model.py:138-159).  Each entry point below
+ * names the reference interface it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Every function returns 0 on success and a negative ddd_status on error;
+ *     ddd_last_error() returns a thread-local human readable message.  No C++
+ *     exception crosses this boundary.
+ *   - `ddd_model*` is an opaque handle owned by the caller until
+ *     ddd_model_destroy().  One handle per host thread / GPU; calls on one
+ *     handle are stream ordered and must not be issued concurrently.
+ *   - Unless marked HOST, pointers are device pointers (HBM) valid on the
+ *     current HIP device.  `stream` is a hipStream_t passed as void* (NULL =
+ *     the default stream).  Nothing here synchronises the device except
+ *     ddd_model_create / ddd_set_forcing (which copy small host tables).
+ *   - Batches are row major [batch][x] ("batch-major"): one sample's N grid
+ *     points are contiguous, so a wavefront's 64 lanes read 256 contiguous
+ *     bytes.  All data arithmetic is IEEE float32 (the reference's TF graph
+ *     dtype); the `_f64` entry points keep the *integration state* in float64
+ *     like SciPy does on the reference's host side.
+ */
+#ifndef DDD1D_H_
+#define DDD1D_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDD_ABI_VERSION 1
+#define DDD_MAX_DERIVATIVES 4 /* Godunov KS uses 4 (equations.py:570-574) */
+#define DDD_MAX_STENCIL 16
+#define DDD_MAX_LAYERS 8
+#define DDD_MAX_STAGES 4
+
+typedef enum ddd_status {
+  DDD_OK = 0,
+  DDD_ERR_INVALID_ARGUMENT = -1,
+  DDD_ERR_UNSUPPORTED = -2,
+  DDD_ERR_HIP = -3,
+  DDD_ERR_NO_DEVICE = -4
+} ddd_status;
+
+/* equations.py: EQUATION_TYPES / CONSERVATIVE_EQUATION_TYPES / FLUX_EQUATION_TYPES
+ * (:590-606).  Derivative order of the entries of `derivative_orders` must be
+ * the class's DERIVATIVE_ORDERS. */
+typedef enum ddd_equation {
+  DDD_EQ_BURGERS = 0,              /* equations.py:230-302  (u_x, u_xx)        */
+  DDD_EQ_BURGERS_CONSERVATIVE = 1, /* equations.py:323-338  (u, u_x)           */
+  DDD_EQ_KDV = 2,                  /* equations.py:373-439  (u_x, u_xxx)       */
+  DDD_EQ_KDV_CONSERVATIVE = 3,     /* equations.py:442-457  (u, u_xx)          */
+  DDD_EQ_KS = 4,                   /* equations.py:481-548  (u_x, u_xx, u_xxxx)*/
+  DDD_EQ_KS_CONSERVATIVE = 5,      /* equations.py:551-567  (u, u_x, u_xxx)    */
+  DDD_EQ_BURGERS_GODUNOV = 6,      /* equations.py:352-370  (u-, u+, u_x)      */
+  DDD_EQ_KDV_GODUNOV = 7,          /* equations.py:460-478  (u-, u+, u_xx)     */
+  DDD_EQ_KS_GODUNOV = 8            /* equations.py:570-587  (u-, u+, u_x, u_xxx)*/
+} ddd_equation;
+
+/* model.py:411-417 (_NONLINEARITIES) */
+typedef enum ddd_activation {
+  DDD_ACT_RELU = 0,
+  DDD_ACT_RELU6 = 1,
+  DDD_ACT_TANH = 2,
+  DDD_ACT_SOFTPLUS = 3,
+  DDD_ACT_ELU = 4
+} ddd_activation;
+
+/* hparams.model_target, model.py:579-640 */
+typedef enum ddd_model_target {
+  DDD_TARGET_COEFFICIENTS = 0,
+  DDD_TARGET_SPACE_DERIVATIVES = 1,
+  DDD_TARGET_TIME_DERIVATIVE = 2,
+  DDD_TARGET_FLUX = 3
+} ddd_model_target;
+
+/* Fixed-step explicit Runge-Kutta schemes.  MIDPOINT is
+ * tf.contrib.integrate.odeint_fixed(method='midpoint') as called from
+ * model.integrate_ode (model.py:155-157); BS3 is the Bogacki-Shampine tableau
+ * of SciPy's RK23 (the reference's production integrator, integrate.py:154)
+ * without step-size control. */
+typedef enum ddd_scheme {
+  DDD_SCHEME_EULER = 0,
+  DDD_SCHEME_MIDPOINT = 1,
+  DDD_SCHEME_BS3 = 2,
+  DDD_SCHEME_RK4 = 3
+} ddd_scheme;
+
+typedef enum ddd_kernel_kind {
+  DDD_KERNEL_AUTO = 0,    /* MFMA path when the configuration allows it */
+  DDD_KERNEL_GENERIC = 1, /* any configuration, scalar FMA, one block / sample */
+  DDD_KERNEL_MFMA = 2     /* f32 MFMA tiles, 256 grid points / block          */
+} ddd_kernel_kind;
+
+/* How ddd_integrate_fixed advances time. */
+typedef enum ddd_launch_mode {
+  DDD_LAUNCH_PERSISTENT = 0, /* time loop inside ONE launch, state in registers */
+  DDD_LAUNCH_PER_SUBSTEP = 1 /* one fused launch per RK substep, state in HBM   */
+} ddd_launch_mode;
+
+/* Static description of one model: the equation (equations.py), the solution
+ * grid (equations.py:44-68) and the conv-net hyper-parameters
+ * (training.py:127-141). */
+typedef struct ddd_config {
+  int32_t struct_size; /* = sizeof(ddd_config), checked */
+  int32_t equation;    /* ddd_equation */
+  int32_t num_points;  /* N = grid.solution_num_points */
+  int32_t num_derivatives;
+  int32_t derivative_orders[DDD_MAX_DERIVATIVES];
+  double dx;                 /* grid.solution_dx */
+  double period;             /* grid.period */
+  double eta;                /* Burgers viscosity, else 0 */
+  double standard_deviation; /* Equation.standard_deviation (input scaling) */
+  int32_t stencil_size;      /* G: 7 centered / 6 staggered by default */
+  int32_t model_target;      /* ddd_model_target */
+  int32_t num_layers;        /* conv layers incl. the linear output layer */
+  int32_t filter_size;       /* hidden channels (32) */
+  int32_t kernel_size;       /* conv taps (5) */
+  int32_t activation;        /* ddd_activation */
+  int32_t polynomial_accuracy_order;    /* 0: net emits D*G coefficients */
+  int32_t ensure_unbiased_coefficients; /* only with accuracy order 0 */
+  int32_t input_sizes[DDD_MAX_DERIVATIVES]; /* null-space dims per derivative */
+  int32_t reserved[4];
+} ddd_config;
+
+typedef struct ddd_model ddd_model;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+
+/* Replaces: SavedModelDifferentiator.__init__ (integrate.py:51-68), i.e.
+ * building model.predict_time_derivative (model.py:618-640) and restoring the
+ * checkpoint.  HOST inputs:
+ *   weights   layer-major; per layer the conv kernel [K][Cin][Cout] (the
+ *             tf.layers.conv1d variable layout) followed by the bias [Cout].
+ *             Cin = 1 for the first layer, filter_size otherwise; Cout =
+ *             filter_size for hidden layers and, for the output layer,
+ *             sum(input_sizes) (coefficients target, accuracy order > 0),
+ *             D*G (accuracy order 0), D (space_derivatives) or 1.
+ *   nullspace per derivative [input_size][G], float32 of
+ *             PolynomialAccuracyLayer.nullspace (polynomials.py:246-264);
+ *             NULL unless target = coefficients with accuracy order > 0.
+ *   bias      [D][G] float32 of PolynomialAccuracyLayer.bias; same condition.
+ */
+int ddd_model_create(const ddd_config* cfg, const float* weights,
+                     size_t n_weights, const float* nullspace,
+                     size_t n_nullspace, const float* bias, size_t n_bias,
+                     ddd_model** out);
+
+/* Replaces: PolynomialDifferentiator.__init__ (integrate.py:77-103) /
+ * model.baseline_space_derivatives (model.py:59-112): fixed stencils.
+ * HOST `stencils` is [D][G] float32, each derivative's standard coefficients
+ * (polynomials.coefficients) centred in a common G-wide window so that tap i
+ * multiplies u[x + i - G/2] (the alignment of layers.pad_periodic(center=True),
+ * layers.py:76-79).  Net fields of cfg are ignored.  Also used for
+ * num_layers = 0 models (model.py:496-502) after folding on the host. */
+int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
+                        size_t n_stencils, ddd_model** out);
+
+int ddd_model_destroy(ddd_model* model);
+
+/* ---- per-sample forcing -------------------------------------------------
+ * Replaces: RandomForcing.__call__ inside finalize_time_derivative
+ * (equations.py:214-219, 276-277), one parameter row per sample.  HOST inputs,
+ * all [batch][nparams]:
+ *   amplitude  a_j            (times the exact block-mean factor when the grid
+ *                              resamples by 'mean', i.e. conservative equations)
+ *   omega      omega_j
+ *   phase      phi_j          (plus the block-centre shift for 'mean')
+ *   k_index    row of `spatial_phase` to use for mode j
+ *   spatial_phase [n_k][N]    float32(2 pi k x_i / period) for each distinct k
+ * forcing_b(x_i, t) = sum_j amplitude * sin((omega*t + spatial_phase) + phase),
+ * accumulated in float32 in that order (the TF graph's order).  Ignored by
+ * equations whose finalize_time_derivative is the identity (KdV, KS). */
+int ddd_set_forcing(ddd_model* model, int batch, int nparams,
+                    const float* amplitude, const float* omega,
+                    const float* phase, const int32_t* k_index,
+                    const float* spatial_phase, int n_k);
+int ddd_clear_forcing(ddd_model* model);
+
+/* ---- the hot path --------------------------------------------------------*/
+
+/* Replaces: Differentiator.__call__(t, y) (integrate.py:70-71, 94-95), batched:
+ * dydt[b] = finalize_time_derivative(t, predict_time_derivative(y[b])).
+ * y, dydt: [batch][N] float32. */
+int ddd_time_derivative(ddd_model* model, double t, const float* y,
+                        float* dydt, int batch, void* stream);
+
+/* ONE fused launch = one Runge-Kutta substep:
+ *     f       = time_derivative(t, y_in)
+ *     y_out   = y_base + c1 * f          (y_base NULL -> c1 * f)
+ *     acc_out = acc_in + c2 * f          (skipped when acc_out NULL;
+ *                                         acc_in NULL -> c2 * f)
+ * All arrays [batch][N] float32; y_out / acc_out may alias their inputs. */
+int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
+                   const float* y_base, float c1, float* y_out,
+                   const float* acc_in, float c2, float* acc_out, int batch,
+                   void* stream);
+
+/* Replaces: model.integrate_ode (model.py:138-159) and, with the controller
+ * pinned at max_step, the solve_ivp loop of integrate.odeint
+ * (integrate.py:154-155) -- for the whole batch at once.
+ * Advances n_steps steps of size dt from (t0, y0); every `save_every` steps
+ * the state is written to y_out[(step+1)/save_every - 1][batch][N]
+ * (n_steps / save_every snapshots).  y0 is not modified. */
+int ddd_integrate_fixed(ddd_model* model, int scheme, int launch_mode,
+                        double t0, double dt, int n_steps, int save_every,
+                        const float* y0, float* y_out, int batch, void* stream);
+
+/* Same, integration state and I/O in float64 (right-hand side stays float32,
+ * as in the reference where SciPy holds y in float64 and TF evaluates in
+ * float32: integrate.py:57-60, 154).  Persistent launch mode only. */
+int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
+                            int n_steps, int save_every, const double* y0,
+                            double* y_out, int batch, void* stream);
+
+/* ---- parity / debugging views of the same kernel ------------------------ */
+
+/* Replaces: model.predict_space_derivatives (model.py:579-600) or
+ * baseline_space_derivatives; out [batch][N][D]. */
+int ddd_space_derivatives(ddd_model* model, const float* y, float* out,
+                          int batch, void* stream);
+
+/* Replaces: model.predict_coefficients (model.py:420-513);
+ * out [batch][N][D][G]. */
+int ddd_coefficients(ddd_model* model, const float* y, float* out, int batch,
+                     void* stream);
+
+/* ---- standalone operators (reference unit-test surface) ------------------ */
+
+/* Replaces: layers.nn_conv1d_periodic / conv1d_periodic_layer
+ * (layers.py:95-137).  in [batch][N][Cin], filters [K][Cin][Cout] (device),
+ * bias [Cout] or NULL, out [batch][N][Cout]; activation -1 = none. */
+int ddd_conv1d_periodic(const float* in, const float* filters,
+                        const float* bias, float* out, int batch, int n,
+                        int cin, int cout, int k, int center, int activation,
+                        void* stream);
+
+/* Replaces: layers.pad_periodic (layers.py:39-83).
+ * in [batch][N][C] -> out [batch][N + padding][C]. */
+int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c,
+                     int padding, int center, void* stream);
+
+/* Replaces: PolynomialAccuracyLayer.apply (polynomials.py:266-277).
+ * inputs [m][input_size], nullspace [input_size][G], bias [G], out [m][G]. */
+int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
+                                  const float* bias, float* out, int64_t m,
+                                  int input_size, int g, void* stream);
+
+/* ---- introspection -------------------------------------------------------*/
+int ddd_set_kernel(ddd_model* model, int kernel_kind);
+/* "mfma_f32" or "generic": the kernel family launches on this handle use. */
+const char* ddd_kernel_name(const ddd_model* model);
+/* Algorithmic multiply-adds per grid point per right-hand-side evaluation
+ * (SURVEY.md section 8(d)); 2x this is the FLOP count used for the roofline. */
+int64_t ddd_fma_per_point(const ddd_model* model);
+/* Number of right-hand-side evaluations per step of a scheme. */
+int ddd_scheme_stages(int scheme);
+/* Runs tiny MFMA probes on the current device and checks the operand/result
+ * register layouts the kernels assume; 0 = layouts as assumed. */
+int ddd_selftest_mfma_layout(void);
+int ddd_abi_version(void);
+const char* ddd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDD1D_H_ */

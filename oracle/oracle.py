@@ -370,6 +370,17 @@ EVALS_PER_STEP = {SCHEME_EULER: 1, SCHEME_MIDPOINT: 2, SCHEME_BS3: 3,
                   SCHEME_RK4: 4}
 
 
+# Explicit RK tableaus in "previous stage only" form (all four schemes have
+# u_s = y + a_s h k_{s-1}):  name -> (a, b, c)
+TABLEAUS = {
+    SCHEME_EULER: ((0.0,), (1.0,), (0.0,)),
+    SCHEME_MIDPOINT: ((0.0, 0.5), (0.0, 1.0), (0.0, 0.5)),
+    SCHEME_BS3: ((0.0, 0.5, 0.75), (2 / 9, 1 / 3, 4 / 9), (0.0, 0.5, 0.75)),
+    SCHEME_RK4: ((0.0, 0.5, 0.5, 1.0), (1 / 6, 1 / 3, 1 / 3, 1 / 6),
+                 (0.0, 0.5, 0.5, 1.0)),
+}
+
+
 def integrate_fixed(spec, scheme, t0, dt, num_steps, save_every, y0,
                     forcing=None, state_dtype=F32, apply_forcing=True):
   """Fixed-step explicit Runge-Kutta over the whole batch.
@@ -378,13 +389,15 @@ def integrate_fixed(spec, scheme, t0, dt, num_steps, save_every, y0,
   tf.contrib.integrate.odeint_fixed(method='midpoint') [tensorflow<2, not in
   /root/reference; restated from its published definition]:
       k1 = f(y, t); k2 = f(y + k1*dt/2, t + dt/2); y <- y + dt*k2
-  with dt cast to the state dtype.  The reference's training-time caller drops
-  the forcing (model.py:655-657); pass apply_forcing=False for that behaviour.
+  with dt cast to the state dtype (multiplying by 1/2 is exact, so
+  k1*(dt/2) == (k1*dt)/2 bit for bit).  The reference's training-time caller
+  drops the forcing (model.py:655-657); pass apply_forcing=False for that.
 
   SCHEME_BS3 is the Bogacki-Shampine tableau SciPy's RK23 uses
   (integrate.py:154-155 pins max_step=0.01; with the controller saturated the
-  accepted steps are exactly these), without error control; f(y_{n+1}) is
-  re-used as the next k1 (FSAL) so a step costs 3 evaluations.
+  accepted steps are exactly these) without error control: 3 evaluations per
+  step.  State update: y' = ((y + b1 h k1) + b2 h k2) + b3 h k3 with the
+  float32 products (b_s h) formed first, in ``state_dtype``.
 
   Returns y [num_saved, batch, x] in ``state_dtype`` where
   num_saved = num_steps // save_every (state after steps save_every, 2*..).
@@ -393,34 +406,20 @@ def integrate_fixed(spec, scheme, t0, dt, num_steps, save_every, y0,
   y = np.asarray(y0).astype(dtype)
   h = dtype(dt)
   frc = forcing if apply_forcing else None
-
-  def f(t, state):
-    return time_derivative(spec, t, state, frc).astype(dtype)
+  a, b, c = TABLEAUS[scheme]
 
   saved = []
-  k_first = None
   for step in range(num_steps):
     t = t0 + step * dt
-    if scheme == SCHEME_EULER:
-      y = y + h * f(t, y)
-    elif scheme == SCHEME_MIDPOINT:
-      k1 = f(t, y)
-      k2 = f(t + dt / 2, y + k1 * h / dtype(2))
-      y = y + h * k2
-    elif scheme == SCHEME_BS3:
-      k1 = f(t, y) if k_first is None else k_first
-      k2 = f(t + dt / 2, y + (h * dtype(0.5)) * k1)
-      k3 = f(t + 0.75 * dt, y + (h * dtype(0.75)) * k2)
-      y = y + h * (dtype(2 / 9) * k1 + dtype(1 / 3) * k2 + dtype(4 / 9) * k3)
-      k_first = f(t + dt, y)
-    elif scheme == SCHEME_RK4:
-      k1 = f(t, y)
-      k2 = f(t + dt / 2, y + (h * dtype(0.5)) * k1)
-      k3 = f(t + dt / 2, y + (h * dtype(0.5)) * k2)
-      k4 = f(t + dt, y + h * k3)
-      y = y + (h / dtype(6)) * (k1 + dtype(2) * k2 + dtype(2) * k3 + k4)
-    else:
-      raise ValueError('unknown scheme {}'.format(scheme))
+    ynew = y
+    kprev = None
+    for s in range(len(a)):
+      us = y if s == 0 else y + kprev.astype(dtype) * (dtype(F32(a[s])) * h)
+      f = time_derivative(spec, t + c[s] * dt, us, frc)
+      if b[s] != 0.0:
+        ynew = ynew + (dtype(F32(b[s])) * h) * f.astype(dtype)
+      kprev = f
+    y = ynew
     if (step + 1) % save_every == 0:
       saved.append(y.copy())
   if not saved:

@@ -1,0 +1,178 @@
+"""Lane-level NumPy emulation of the MFMA kernel's data movement (no GPU).
+
+Transcribes, formula by formula, (a) the weight packing of
+csrc/capi.hip::pack_mfma_weights, (b) the operand gathers / result scatters of
+csrc/rhs_mfma.h (input_layer, hidden_layer, final_layer) and (c) the CDNA4
+f32 MFMA register layouts the kernels assume
+(cdna_hip_programming.md section 3):
+
+  v_mfma_f32_32x32x2_f32 : lane l supplies A[i = l & 31][k = l >> 5] and
+      B[k = l >> 5][j = l & 31]; register r of lane l holds
+      D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
+  v_mfma_f32_16x16x4_f32 : lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15];
+      register r of lane l holds D[4 (l >> 4) + r][l & 15].
+
+and checks that the composition equals the oracle's conv tower.  The layouts
+themselves are verified on hardware by ddd_selftest_mfma_layout.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import oracle  # noqa: E402
+
+ROWS, HS = 256, 36
+LANES = np.arange(64)
+
+
+def mfma32(a, b, acc):
+  """acc[lane, r] += D-layout of A(32x2) @ B(2x32)."""
+  A = np.stack([a[:32], a[32:]], axis=1).astype(np.float64)     # [i, k]
+  B = np.stack([b[:32], b[32:]], axis=0).astype(np.float64)     # [k, j]
+  D = A @ B
+  for r in range(16):
+    i = (r & 3) + 8 * (r >> 2) + 4 * (LANES >> 5)
+    acc[:, r] += D[i, LANES & 31]
+  return acc
+
+
+def mfma16(a, b, acc):
+  A = a.reshape(4, 16).T.astype(np.float64)      # [i, k]: lane = i + 16 k
+  B = b.reshape(4, 16).astype(np.float64)        # [k, j]: lane = j + 16 k
+  D = A @ B
+  for r in range(4):
+    acc[:, r] += D[4 * (LANES >> 4) + r, LANES & 15]
+  return acc
+
+
+def pack_input(w, b):          # capi.hip: input layer
+  packed = np.zeros((3, 64))
+  for s in range(3):
+    for lane in range(64):
+      k, ch = 2 * s + (lane >> 5), lane & 31
+      packed[s, lane] = w[k, 0, ch] if k < 5 else b[ch]
+  return packed
+
+
+def pack_hidden(w, b):         # capi.hip: hidden layer
+  packed = np.zeros((81, 64))
+  for s in range(80):
+    tap, jj = s // 16, s % 16
+    for lane in range(64):
+      cin, cout = 16 * (lane >> 5) + jj, lane & 31
+      packed[s, lane] = w[tap, cin, cout]
+  for lane in range(64):
+    packed[80, lane] = b[lane & 31] if (lane >> 5) == 0 else 0.0
+  return packed
+
+
+def pack_final(w, b, c_out):   # capi.hip: output layer
+  packed = np.zeros((41, 64))
+  for s in range(40):
+    tap, jj = s // 8, s % 8
+    for lane in range(64):
+      cin, cout = 8 * (lane >> 4) + jj, lane & 15
+      packed[s, lane] = w[tap, cin, cout] if cout < c_out else 0.0
+  for lane in range(64):
+    cout = lane & 15
+    packed[40, lane] = b[cout] if ((lane >> 4) == 0 and cout < c_out) else 0.0
+  return packed
+
+
+def tile_src_row(trow, off, n, rows_used):
+  """rhs_mfma.h::tile_src_row (vectorised over lanes)."""
+  inv_n = np.float32(1.0) / np.float32(n)
+  sl = ((trow.astype(np.float32) + np.float32(0.5)) * inv_n).astype(np.int32)
+  base = sl * n
+  q = trow - base + off
+  q = np.where(q < 0, q + n, q)
+  q = np.where(q >= n, q - n, q)
+  return np.where(trow < rows_used, base + q, trow)
+
+
+def store_tile32(buf, trow, half, acc):
+  for qd in range(4):
+    for c in range(4):
+      buf[trow, 8 * qd + 4 * half + c] = acc[:, 4 * qd + c]
+
+
+def emulate_tower(un_rows, n, kernels, biases, c_out):
+  """un_rows: [256] already divided by the std.  Returns net [256, 16]."""
+  rows_used = (ROWS // n) * n
+  relu = lambda x: np.maximum(x, 0.0)
+  hA = np.zeros((ROWS, HS))
+  hB = np.zeros((ROWS, HS))
+  w_in = pack_input(kernels[0], biases[0])
+  # ---- input layer -------------------------------------------------------
+  for wave in range(4):
+    j, half = LANES & 31, LANES >> 5
+    for t in range(2):
+      trow = wave * 64 + t * 32 + j
+      b0 = un_rows[tile_src_row(trow, half - 2, n, rows_used)]
+      b1 = un_rows[tile_src_row(trow, half, n, rows_used)]
+      b2 = np.where(half == 1, 1.0, un_rows[tile_src_row(trow, 2, n, rows_used)])
+      acc = np.zeros((64, 16))
+      for s, bop in enumerate((b0, b1, b2)):
+        acc = mfma32(w_in[s], bop, acc)
+      store_tile32(hA, trow, half, relu(acc))
+  src, dst = hA, hB
+  # ---- hidden layers -------------------------------------------------------
+  for l in range(1, len(kernels) - 1):
+    w_h = pack_hidden(kernels[l], biases[l])
+    dst[:] = 0
+    for wave in range(4):
+      j, half = LANES & 31, LANES >> 5
+      for t in range(2):
+        trow = wave * 64 + t * 32 + j
+        acc = np.zeros((64, 16))
+        for g in range(20):
+          tap, quad = g >> 2, g & 3
+          rows = tile_src_row(trow, tap - 2, n, rows_used)
+          for c in range(4):
+            bop = src[rows, 16 * half + 4 * quad + c]
+            acc = mfma32(w_h[4 * g + c], bop, acc)
+        acc = mfma32(w_h[80], np.ones(64), acc)
+        store_tile32(dst, trow, half, relu(acc))
+    src, dst = dst, src
+  # ---- output layer ----------------------------------------------------------
+  w_f = pack_final(kernels[-1], biases[-1], c_out)
+  for wave in range(4):
+    j, quarter = LANES & 15, LANES >> 4
+    for t in range(4):
+      trow = wave * 64 + t * 16 + j
+      acc = np.zeros((64, 4))
+      for tap in range(5):
+        rows = tile_src_row(trow, tap - 2, n, rows_used)
+        for i in range(8):
+          acc = mfma16(w_f[tap * 8 + i], src[rows, 8 * quarter + i], acc)
+      acc = mfma16(w_f[40], np.ones(64), acc)
+      for r in range(4):
+        dst[trow, 4 * quarter + r] = acc[:, r]
+  return dst[:, :16]
+
+
+@pytest.mark.parametrize('n,num_layers,c_out', [(64, 3, 9), (32, 3, 11),
+                                                 (48, 2, 8), (256, 4, 16),
+                                                 (100, 3, 9)])
+def test_emulated_tower_matches_oracle(n, num_layers, c_out):
+  rs = np.random.RandomState(n + num_layers)
+  shapes = [(5, 1 if l == 0 else 32, c_out if l == num_layers - 1 else 32)
+            for l in range(num_layers)]
+  kernels = [rs.randn(*s).astype(np.float32) * 0.3 for s in shapes]
+  biases = [rs.randn(s[2]).astype(np.float32) * 0.1 for s in shapes]
+  samples = ROWS // n
+  u = rs.randn(samples, n).astype(np.float32)
+  spec = dict(standard_deviation=0.8, conv_kernels=kernels, conv_biases=biases,
+              num_layers=num_layers, nonlinearity='relu')
+  want = oracle.conv_stack(u, spec)                      # [samples, n, c_out]
+  un_rows = np.zeros(ROWS)
+  un_rows[:samples * n] = (u / np.float32(0.8)).reshape(-1)
+  net = emulate_tower(un_rows, n, kernels, biases, c_out)
+  got = net[:samples * n, :c_out].reshape(samples, n, c_out)
+  np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+  # padded output channels stay exactly zero
+  assert np.all(net[:samples * n, c_out:] == 0)

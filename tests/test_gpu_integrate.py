@@ -1,0 +1,187 @@
+"""Time stepping on the GPU vs the oracle and vs reference-generated goldens."""
+import numpy as np
+import pytest
+
+from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err)
+from ddd1d_amd import equations, integrate, model as model_lib
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5   # north_star: float32 trajectories within 1e-5 rel of the reference
+
+SCHEMES = {'euler': oracle.SCHEME_EULER, 'midpoint': oracle.SCHEME_MIDPOINT,
+           'bs3': oracle.SCHEME_BS3, 'rk4': oracle.SCHEME_RK4}
+
+
+@pytest.mark.parametrize('scheme', ['euler', 'midpoint', 'bs3', 'rk4'])
+@pytest.mark.parametrize('kernel', ['mfma', 'generic'])
+def test_fixed_step_schemes_vs_oracle(scheme, kernel):
+  model = make_model('burgers', True, num_points=64, resample_factor=8)
+  model.set_kernel(kernel)
+  batch = 6
+  forcing = batch_forcing(batch)
+  model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, batch)
+  dt = 1e-3 if scheme in ('euler', 'midpoint') else 1e-2
+  got = model.integrate_fixed(y0, 40, dt=dt, t0=0.5, scheme=scheme,
+                              save_every=10).cpu().numpy()
+  want = oracle.integrate_fixed(model.spec(), SCHEMES[scheme], 0.5, dt, 40, 10,
+                                y0, forcing=forcing)
+  assert got.shape == want.shape == (4, batch, 64)
+  err = rel_err(got, want)
+  print(scheme, kernel, 'trajectory rel err {:.2e}'.format(err))
+  assert err < TOL
+
+
+@pytest.mark.parametrize('equation,conservative,dt,steps', [
+    ('kdv', False, 2.5e-5, 60), ('kdv', True, 2.5e-5, 60),
+    ('ks', False, 2.5e-5, 60), ('ks', True, 2.5e-5, 60),
+    ('burgers', False, 1e-3, 60),
+])
+def test_midpoint_other_equations(equation, conservative, dt, steps):
+  """model.integrate_ode semantics (model.py:138-159) with equation.time_step."""
+  n = 256 if equation == 'ks' else 64
+  model = make_model(equation, conservative, num_points=n, resample_factor=1)
+  assert model.equation.time_step == dt
+  y0 = random_phase_ic(model.equation, 3)
+  got = model_lib.integrate_ode(model, y0, steps, dt).cpu().numpy()
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt,
+                                steps, 1, y0)
+  assert got.shape == (3, n, steps)            # [batch, x, time] like the reference
+  err = rel_err(got, np.transpose(want, (1, 2, 0)))
+  print(equation, conservative, 'rel err {:.2e}'.format(err))
+  assert err < TOL
+
+
+def test_launch_modes_agree():
+  """One launch per substep (state in HBM) == persistent launch (state in VGPRs)."""
+  model = make_model('burgers', True, num_points=64)
+  forcing = batch_forcing(9)
+  model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, 9)
+  for scheme in ('midpoint', 'bs3', 'rk4', 'euler'):
+    a = model.integrate_fixed(y0, 12, dt=1e-3, scheme=scheme, save_every=4,
+                              launch_mode='persistent').cpu().numpy()
+    b = model.integrate_fixed(y0, 12, dt=1e-3, scheme=scheme, save_every=4,
+                              launch_mode='per_substep').cpu().numpy()
+    np.testing.assert_array_equal(a, b)
+
+
+def test_rk_substep_composes_midpoint():
+  """ddd_rk_substep x2 == one midpoint step of ddd_integrate_fixed."""
+  import torch
+  model = make_model('kdv', False, num_points=64)
+  y0 = torch.from_numpy(random_phase_ic(model.equation, 5)).cuda()
+  dt = 2.5e-5
+  ymid = torch.empty_like(y0)
+  y1 = torch.empty_like(y0)
+  model.rk_substep(0.0, y0, y_base=y0, c1=dt / 2, y_out=ymid)
+  model.rk_substep(dt / 2, ymid, y_base=y0, c1=dt, y_out=y1)
+  want = model.integrate_fixed(y0, 1, dt=dt, scheme='midpoint')[0]
+  np.testing.assert_array_equal(y1.cpu().numpy(), want.cpu().numpy())
+  # accumulator form
+  acc = torch.empty_like(y0)
+  model.rk_substep(dt / 2, ymid, acc_in=y0, c2=dt, acc_out=acc)
+  np.testing.assert_array_equal(acc.cpu().numpy(), want.cpu().numpy())
+
+
+def test_float64_state():
+  model = make_model('burgers', False, num_points=64)
+  forcing = batch_forcing(4)
+  model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, 4).astype(np.float64)
+  got = model.integrate_fixed(y0, 30, dt=1e-2, scheme='bs3', save_every=30,
+                              state_dtype='float64').cpu().numpy()
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_BS3, 0.0, 1e-2, 30,
+                                30, y0, forcing=forcing, state_dtype=np.float64)
+  assert got.dtype == np.float64
+  assert rel_err(got, want) < TOL
+
+
+def test_save_every_and_zero_steps():
+  model = make_model('burgers', True, num_points=64)
+  y0 = random_phase_ic(model.equation, 3)
+  full = model.integrate_fixed(y0, 12, dt=1e-3, save_every=1).cpu().numpy()
+  sparse = model.integrate_fixed(y0, 12, dt=1e-3, save_every=5).cpu().numpy()
+  assert sparse.shape[0] == 2
+  np.testing.assert_array_equal(sparse[0], full[4])
+  np.testing.assert_array_equal(sparse[1], full[9])
+  none = model.integrate_fixed(y0, 0, dt=1e-3)
+  assert tuple(none.shape) == (0, 3, 64)
+
+
+def test_scipy_rk23_with_hip_differentiator_matches_oracle():
+  """integrate.odeint (SciPy RK23, float64 state) driving the HIP RHS, B = 1:
+  the reference's production execution shape (integrate.py:143-169)."""
+  model = make_model('burgers', True, num_points=32, resample_factor=16, seed=4)
+  eq = model.equation
+  diff = integrate.SavedModelDifferentiator(None, eq, model=model)
+  times = np.linspace(0, 0.5, 6)
+  y0 = eq.initial_value()
+  got, nfev = integrate.odeint(y0, diff, times)
+  forcing = model_lib.forcing_from_equations([eq])
+  want, nfev_want = oracle.odeint_rk23(model.spec(), y0, times,
+                                       {k: v[0] for k, v in forcing.items()})
+  assert nfev == nfev_want
+  assert rel_err(got, want) < TOL
+
+
+GOLDEN_ODEINT = [
+    ('BurgersEquation', 32, 1, 0, 1), ('ConservativeBurgersEquation', 64, 4, 2, 1),
+    ('KdVEquation', 64, 1, 1, 1), ('ConservativeKdVEquation', 64, 4, 5, 1),
+    ('KSEquation', 64, 1, 4, 1), ('ConservativeKSEquation', 64, 2, 7, 1),
+    ('BurgersEquation', 32, 1, 9, 3),
+]
+
+
+@pytest.mark.parametrize('cls_name,n,rf,seed,acc', GOLDEN_ODEINT)
+def test_integrate_baseline_vs_reference_golden(golden, cls_name, n, rf, seed, acc):
+  """integrate_baseline through the HIP kernel against trajectories produced by
+  the reference's own odeint + equation_of_motion + finalize (float64 RHS).
+  Config 1 of BASELINE.json is the first case (Burgers N=32, 100 RK23 steps)."""
+  key = 'odeint/{}/n{}/rf{}/s{}/a{}'.format(cls_name, n, rf, seed, acc)
+  eq = getattr(equations, cls_name)(n, resample_factor=rf, random_seed=seed)
+  times = golden[key + '/times']
+  ds = integrate.integrate_baseline(eq, times=times, accuracy_order=acc)
+  want = golden[key + '/y']
+  got = np.asarray(ds['y'])
+  assert got.shape == want.shape
+  # the reference evaluates the RHS in float32 inside TF; the golden RHS is
+  # float64, so allow the float32 RHS noise on top of 1e-5
+  assert rel_err(got, want) < 5e-5
+  assert int(ds.coords['num_evals']) == int(golden[key + '/nfev'])
+  # single RHS evaluation as well
+  diff = integrate.PolynomialDifferentiator(eq, acc)
+  y_probe = eq.initial_value() + 0.1 * np.sin(eq.grid.solution_x)
+  rhs = diff(0.1, y_probe)
+  rhs_tol = 2e-3 if 'KS' in cls_name else 2e-5
+  assert rel_err(rhs, golden[key + '/rhs_t0.1_y0']) < rhs_tol
+
+
+def test_integrate_batch_matches_per_sample_scipy():
+  """Batched fixed-step BS3 at dt = max_step reproduces the adaptive RK23 runs
+  of the reference while its controller sits at max_step (smooth Burgers)."""
+  hp_model = make_model('burgers', True, num_points=32, resample_factor=16)
+  batch = 3
+  times = np.linspace(0, 0.2, 3)
+  forcing = batch_forcing(batch, seed0=11)
+  y0 = random_phase_ic(hp_model.equation, batch)
+  ds = integrate.integrate_batch(hp_model, y0, times, dt=0.01, scheme='bs3',
+                                 forcing=forcing, state_dtype='float64')
+  y = np.asarray(ds['y'])
+  assert y.shape == (batch, 3, 32)
+  for b in range(batch):
+    one = {k: v[b] for k, v in forcing.items()}
+    want, _ = oracle.odeint_rk23(hp_model.spec(), y0[b], times, one)
+    # adaptive vs fixed stepping differ in the first (small) steps: 1e-4
+    assert rel_err(y[b], want) < 2e-4
+
+
+def test_mean_conservation_long_run():
+  """integrate_test.py:101-104: conservative forms keep the spatial mean."""
+  model = make_model('kdv', True, num_points=64, resample_factor=1)
+  y0 = random_phase_ic(model.equation, 64)
+  out = model.integrate_fixed(y0, 400, dt=2.5e-5, save_every=400).cpu().numpy()
+  drift = np.abs(out[0].mean(axis=1) - y0.mean(axis=1)).max()
+  assert np.isfinite(out).all()
+  assert drift < 1e-5

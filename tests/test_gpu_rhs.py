@@ -1,0 +1,228 @@
+"""The fused right-hand-side kernel vs the CPU oracle, through the C ABI.
+
+Tolerance: north_star asks for float32 results within 1e-5 (relative) of the
+reference.  Single evaluations are compared in the max norm relative to the
+largest reference value.  The MFMA / generic kernels and the oracle all use
+IEEE float32 but sum in different orders, so the irreducible difference is a
+few float32 ulps times the cancellation in the stencil apply (coefficients of
+size 1/dx^d multiply O(1) values that cancel); TOL_RHS below is that bound and
+is asserted, the measured value is printed.
+"""
+import numpy as np
+import pytest
+
+from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err)
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # Burgers / KdV: north_star's float32 tolerance
+TOL_KS = 2e-4       # KS: 4th derivative stencils (|c| ~ 6/dx^4) on smooth data
+                    # cancel ~1e4-fold; see test_f32_noise_floor_ks
+
+ALL_EQUATIONS = [
+    ('burgers', False, False), ('burgers', True, False), ('burgers', True, True),
+    ('kdv', False, False), ('kdv', True, False), ('kdv', True, True),
+    ('ks', False, False), ('ks', True, False), ('ks', True, True),
+]
+
+
+def _tol(equation):
+  return TOL_KS if equation == 'ks' else TOL
+
+
+def _check_all_views(model, y0, t, forcing, tol):
+  spec = model.spec()
+  got = model.time_derivative(y0, t).cpu().numpy()
+  want = oracle.time_derivative(spec, t, y0, forcing)
+  err = rel_err(got, want)
+  assert np.isfinite(got).all()
+  assert err < tol, ('time_derivative', model.kernel_name, err)
+  if spec.get('model_target', 'coefficients') in ('coefficients', 'space_derivatives'):
+    d_got = model.space_derivatives(y0).cpu().numpy()
+    d_want = oracle.predict_space_derivatives(y0, spec)
+    for d in range(d_want.shape[-1]):
+      e = rel_err(d_got[..., d], d_want[..., d])
+      assert e < 10 * tol, ('space_derivatives', d, model.kernel_name, e)
+  if spec.get('model_target', 'coefficients') == 'coefficients':
+    c_got = model.coefficients(y0).cpu().numpy()
+    c_want = oracle.predict_coefficients(y0, spec)
+    assert c_got.shape == c_want.shape
+    assert rel_err(c_got, c_want) < 1e-5, ('coefficients', model.kernel_name)
+  return err
+
+
+@pytest.mark.parametrize('kernel', ['mfma', 'generic'])
+@pytest.mark.parametrize('equation,conservative,numerical_flux', ALL_EQUATIONS)
+def test_time_derivative_all_equations(equation, conservative, numerical_flux,
+                                       kernel):
+  model = make_model(equation, conservative, numerical_flux, num_points=64,
+                     resample_factor=4, seed=3)
+  model.set_kernel(kernel)
+  assert model.kernel_name == ('mfma_f32' if kernel == 'mfma' else 'generic')
+  batch = 7    # not a multiple of the 4 samples per workgroup
+  y0 = random_phase_ic(model.equation, batch)
+  forcing = batch_forcing(batch, seed0=50)
+  model.set_forcing(forcing)
+  err = _check_all_views(model, y0, 0.37, forcing, _tol(equation))
+  print('{} cons={} flux={} {}: rel err {:.2e}'.format(
+      equation, conservative, numerical_flux, kernel, err))
+
+
+@pytest.mark.parametrize('num_points,batch', [(32, 9), (48, 6), (128, 3),
+                                              (256, 2), (200, 2), (16, 33)])
+def test_grid_sizes_mfma(num_points, batch):
+  """Rows per workgroup = floor(256 / N) samples, incl. non-power-of-two N."""
+  model = make_model('burgers', True, num_points=num_points, resample_factor=2)
+  assert model.kernel_name == 'mfma_f32'
+  y0 = random_phase_ic(model.equation, batch)
+  forcing = batch_forcing(batch)
+  model.set_forcing(forcing)
+  _check_all_views(model, y0, 1.25, forcing, TOL)
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=2), dict(num_layers=4), dict(num_layers=5),
+    dict(nonlinearity='relu6'), dict(nonlinearity='tanh'),
+    dict(nonlinearity='softplus'), dict(nonlinearity='elu'),
+    dict(polynomial_accuracy_order=2), dict(polynomial_accuracy_order=3),
+    dict(polynomial_accuracy_scale=0.5),
+])
+def test_network_variants_mfma(overrides):
+  model = make_model('burgers', False, num_points=64, **overrides)
+  assert model.kernel_name == 'mfma_f32', overrides
+  y0 = random_phase_ic(model.equation, 5)
+  forcing = batch_forcing(5)
+  model.set_forcing(forcing)
+  tol = TOL
+  mfma_err = _check_all_views(model, y0, 0.1, forcing, tol)
+  model.set_kernel('generic')
+  generic_err = _check_all_views(model, y0, 0.1, forcing, tol)
+  print(overrides, mfma_err, generic_err)
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=1), dict(filter_size=16), dict(kernel_size=3),
+    dict(kernel_size=4), dict(coefficient_grid_min_size=9),
+    dict(polynomial_accuracy_order=0),
+    dict(polynomial_accuracy_order=0, ensure_unbiased_coefficients=True),
+    dict(model_target='space_derivatives'),
+    dict(model_target='time_derivative'), dict(model_target='flux'),
+    dict(num_layers=0),
+])
+def test_generic_only_variants(overrides):
+  """Configurations enumerated by training_test.py:54-83 that the MFMA path
+  does not cover run on the generic kernel (never on the CPU)."""
+  conservative = not overrides.get('ensure_unbiased_coefficients', False)
+  model = make_model('burgers', conservative, num_points=64, **overrides)
+  if overrides.get('num_layers', 3) != 0:
+    assert model.kernel_name == 'generic', overrides
+    with pytest.raises(Exception, match='MFMA path unavailable'):
+      model.set_kernel('mfma')
+  y0 = random_phase_ic(model.equation, 3)
+  forcing = batch_forcing(3)
+  model.set_forcing(forcing)
+  tol = 1e-4 if overrides.get('polynomial_accuracy_order', 1) == 0 else TOL
+  _check_all_views(model, y0, 0.2, forcing, tol)
+
+
+def test_unforced_and_zero_state():
+  model = make_model('burgers', True, num_points=64)
+  y0 = np.zeros((4, 64), np.float32)        # the reference's Burgers IC
+  got = model.time_derivative(y0, 0.0).cpu().numpy()
+  want = oracle.time_derivative(model.spec(), 0.0, y0, None)
+  assert rel_err(got, want) < TOL or np.abs(want).max() < 1e-6
+  forcing = batch_forcing(4)
+  model.set_forcing(forcing)
+  got = model.time_derivative(y0, 2.0).cpu().numpy()
+  want = oracle.time_derivative(model.spec(), 2.0, y0, forcing)
+  assert rel_err(got, want) < TOL
+  model.set_forcing(None)
+  got = model.time_derivative(y0, 2.0).cpu().numpy()
+  assert np.abs(got).max() < 1e-5
+
+
+def test_forcing_resample_factors():
+  """Block-mean forcing folded into amplitude/phase vs the reference-grid sum."""
+  for rf in (1, 2, 8, 16):
+    for conservative in (False, True):
+      model = make_model('burgers', conservative, num_points=32,
+                         resample_factor=rf)
+      forcing = batch_forcing(6, seed0=rf)
+      model.set_forcing(forcing)
+      y0 = np.zeros((6, 32), np.float32)
+      for t in (0.0, 3.3, 47.0):
+        got = model.time_derivative(y0, t).cpu().numpy()
+        want = oracle.time_derivative(model.spec(), t, y0, forcing)
+        # |forcing| ~ 1; float32 phase rounding at t = 47 is ~4e-6 per mode
+        assert np.abs(got - want).max() < 2e-5, (rf, conservative, t)
+
+
+def test_empty_batch_and_bad_shapes():
+  model = make_model('burgers', True, num_points=64)
+  out = model.time_derivative(np.zeros((0, 64), np.float32), 0.0)
+  assert tuple(out.shape) == (0, 64)
+  with pytest.raises(ValueError, match='unexpected size'):
+    model.time_derivative(np.zeros((2, 32), np.float32), 0.0)
+  model.set_forcing(batch_forcing(2))
+  with pytest.raises(Exception, match='exceeds'):
+    model.time_derivative(np.zeros((3, 64), np.float32), 0.0)
+
+
+def test_nan_propagates():
+  """Divergence is signalled by NaN, never clamped (integrate.py:161-167)."""
+  model = make_model('burgers', True, num_points=64)
+  y0 = random_phase_ic(model.equation, 4)
+  y0[2, 10] = np.nan
+  got = model.time_derivative(y0, 0.0).cpu().numpy()
+  assert np.isnan(got[2]).any()
+  assert np.isfinite(got[[0, 1, 3]]).all()
+
+
+def test_batch_independence_and_determinism():
+  """Samples never interact: permuting the batch permutes the result bit-exactly."""
+  model = make_model('kdv', True, num_points=64)
+  y0 = random_phase_ic(model.equation, 37)
+  a = model.time_derivative(y0, 0.0).cpu().numpy()
+  b = model.time_derivative(y0, 0.0).cpu().numpy()
+  np.testing.assert_array_equal(a, b)
+  perm = np.random.RandomState(0).permutation(37)
+  c = model.time_derivative(y0[perm], 0.0).cpu().numpy()
+  np.testing.assert_array_equal(a[perm], c)
+
+
+def test_mfma_matches_generic_closely():
+  model = make_model('ks', True, num_points=256, resample_factor=1)
+  y0 = random_phase_ic(model.equation, 3)
+  a = model.time_derivative(y0, 0.0).cpu().numpy()
+  model.set_kernel('generic')
+  b = model.time_derivative(y0, 0.0).cpu().numpy()
+  assert rel_err(a, b) < TOL_KS
+
+
+def test_f32_noise_floor_ks():
+  """Documents why KS gets a looser bound: the float32 oracle itself differs
+  from a float64 evaluation of the same formulas by more than 1e-5."""
+  model = make_model('ks', False, num_points=64)
+  spec = model.spec()
+  y0 = random_phase_ic(model.equation, 4)
+  f32 = oracle.time_derivative(spec, 0.0, y0, None)
+  coeff = oracle.predict_coefficients(y0, spec).astype(np.float64)
+  patches = oracle.extract_patches(y0.astype(np.float64), coeff.shape[3])
+  derivs = np.einsum('bxdi,bxi->bxd', coeff, patches)
+  f64 = oracle.equation_of_motion(spec['equation'], y0.astype(np.float64),
+                                  derivs, spec['eta'], spec['dx'])
+  floor = rel_err(f32, f64)
+  got = model.time_derivative(y0, 0.0).cpu().numpy()
+  print('KS float32 noise floor {:.2e}; HIP vs f64 {:.2e}'.format(
+      floor, rel_err(got, f64)))
+  assert rel_err(got, f64) < max(4 * floor, TOL)
+
+
+def test_conservation_large_batch():
+  """Flux-form equations conserve the mean: sum_x u_t = 0 up to rounding
+  (integrate_test.py:101-104, 183-185 check this on trajectories)."""
+  model = make_model('burgers', True, num_points=64)
+  batch = 4096
+  y0 = random_phase_ic(model.equation, batch)
+  got = model.time_derivative(y0, 0.0).cpu().numpy().astype(np.float64)
+  assert np.abs(got.sum(axis=1)).max() < 1e-3 * np.abs(got).max()
