@@ -117,6 +117,12 @@ def load_library(path: Optional[str] = None):
   if _lib is not None and path is None:
     return _lib
   path = path or LIBRARY_PATH
+  # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname
+  # libamdhip64.so.7).  Import torch FIRST so that libddd1d.so binds to that
+  # already-loaded runtime: torch owns the device context, allocations and
+  # streams this library is handed.  Loading libddd1d.so first would pull in
+  # /opt/rocm's copy as a second, separate runtime in the same process.
+  import torch  # noqa: F401  pylint: disable=unused-import
   if not os.path.exists(path):
     raise ImportError(
         'HIP library {} not found: build it with '

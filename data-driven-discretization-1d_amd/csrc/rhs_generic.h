@@ -93,7 +93,11 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
   }
 
   const int gl = p.G / 2;
-  const bool needs_flux_diff = p.conservative || p.target == TARGET_FLUX;
+  // the staggered flux difference applies to flux-form equations of motion and
+  // to the 'flux' model target, never to a directly predicted time derivative
+  const bool direct_time = !p.fixed && p.target == TARGET_TIME_DERIVATIVE;
+  const bool needs_flux_diff =
+      !direct_time && (p.conservative || (!p.fixed && p.target == TARGET_FLUX));
   for (int pos = tid; pos < n; pos += kThreads) {
     const float y = c.u[pos];
     float r;

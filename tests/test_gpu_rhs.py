@@ -190,13 +190,30 @@ def test_batch_independence_and_determinism():
   np.testing.assert_array_equal(a[perm], c)
 
 
+def _f64_truth(spec, y0):
+  """Same formulas in float64 from the float32 coefficients (no forcing)."""
+  coeff = oracle.predict_coefficients(y0, spec).astype(np.float64)
+  patches = oracle.extract_patches(y0.astype(np.float64), coeff.shape[3])
+  derivs = np.einsum('bxdi,bxi->bxd', coeff, patches)
+  return oracle.equation_of_motion(spec['equation'], y0.astype(np.float64),
+                                   derivs, spec['eta'], spec['dx'])
+
+
 def test_mfma_matches_generic_closely():
+  """BASELINE config 4 shape (KS N=256): both kernel families sit inside the
+  float32 noise band around the float64 evaluation of the same formulas."""
   model = make_model('ks', True, num_points=256, resample_factor=1)
+  spec = model.spec()
   y0 = random_phase_ic(model.equation, 3)
+  truth = _f64_truth(spec, y0)
+  floor = rel_err(oracle.time_derivative(spec, 0.0, y0, None), truth)
   a = model.time_derivative(y0, 0.0).cpu().numpy()
   model.set_kernel('generic')
   b = model.time_derivative(y0, 0.0).cpu().numpy()
-  assert rel_err(a, b) < TOL_KS
+  print('KS N=256: oracle-f32 floor {:.2e}, mfma {:.2e}, generic {:.2e}'.format(
+      floor, rel_err(a, truth), rel_err(b, truth)))
+  assert rel_err(a, truth) < max(4 * floor, TOL)
+  assert rel_err(b, truth) < max(4 * floor, TOL)
 
 
 def test_f32_noise_floor_ks():
@@ -206,11 +223,7 @@ def test_f32_noise_floor_ks():
   spec = model.spec()
   y0 = random_phase_ic(model.equation, 4)
   f32 = oracle.time_derivative(spec, 0.0, y0, None)
-  coeff = oracle.predict_coefficients(y0, spec).astype(np.float64)
-  patches = oracle.extract_patches(y0.astype(np.float64), coeff.shape[3])
-  derivs = np.einsum('bxdi,bxi->bxd', coeff, patches)
-  f64 = oracle.equation_of_motion(spec['equation'], y0.astype(np.float64),
-                                  derivs, spec['eta'], spec['dx'])
+  f64 = _f64_truth(spec, y0)
   floor = rel_err(f32, f64)
   got = model.time_derivative(y0, 0.0).cpu().numpy()
   print('KS float32 noise floor {:.2e}; HIP vs f64 {:.2e}'.format(
