@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -118,18 +119,18 @@ struct ddd_model {
   bool mfma_ok = false;
   std::string mfma_reason;
   int kernel = DDD_KERNEL_GENERIC;   // resolved family
+  int force_rows = 0;                // 0 = automatic; 64 / 256 for A/B runs
   int64_t fma_per_point = 0;
   // device allocations
   float* d_weights = nullptr;
   float* d_nullspace = nullptr;
   float* d_bias = nullptr;
-  float* d_nullspace8 = nullptr;
-  float* d_bias8 = nullptr;
   float* d_w_input = nullptr;
   float* d_w_hidden = nullptr;
   float* d_w_final = nullptr;
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
+  float* d_trig = nullptr;
   // scratch for the per-substep launch mode
   float* d_scratch = nullptr;
   size_t scratch_floats = 0;
@@ -173,29 +174,25 @@ void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
   dp->conservative = is_conservative(cfg.equation) ? 1 : 0;
 }
 
-// Tables zero-padded to 8 stencil columns for the MFMA-path epilogue.
+// Tables zero-padded to 8 stencil columns for the MFMA-path epilogue; they
+// travel inside DevParams (kernel-argument segment).
 int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias) {
-  const ddd::DevParams& dp = m->dp;
-  std::vector<float> b8((size_t)dp.D * ddd::kGMax, 0.0f);
+  ddd::DevParams& dp = m->dp;
+  std::memset(dp.ns8, 0, sizeof(dp.ns8));
+  std::memset(dp.bias8, 0, sizeof(dp.bias8));
+  dp.dsel_bits = 0;
+  dp.dsel_valid = 0;
   for (int d = 0; d < dp.D; ++d)
-    for (int g = 0; g < dp.G; ++g) b8[d * ddd::kGMax + g] = bias[d * dp.G + g];
-  int rc = upload(b8, &m->d_bias8);
-  if (rc) return rc;
-  m->dp.bias8 = m->d_bias8;
+    for (int g = 0; g < dp.G; ++g) dp.bias8[d][g] = bias[d * dp.G + g];
   if (nullspace != nullptr) {
-    int total_in = 0;
-    for (int d = 0; d < dp.D; ++d) total_in += dp.in_size[d];
-    std::vector<float> n8((size_t)total_in * ddd::kGMax, 0.0f);
-    int row = 0;
-    for (int d = 0; d < dp.D; ++d) {
-      m->dp.ns8_off[d] = row * ddd::kGMax;
-      for (int j = 0; j < dp.in_size[d]; ++j, ++row)
+    for (int d = 0; d < dp.D; ++d)
+      for (int j = 0; j < dp.in_size[d]; ++j) {
+        const int c = dp.in_start[d] + j;
+        dp.dsel_bits |= (unsigned)d << (2 * c);
+        dp.dsel_valid |= 1u << c;
         for (int g = 0; g < dp.G; ++g)
-          n8[(size_t)row * ddd::kGMax + g] = nullspace[dp.ns_off[d] + j * dp.G + g];
-    }
-    rc = upload(n8, &m->d_nullspace8);
-    if (rc) return rc;
-    m->dp.nullspace8 = m->d_nullspace8;
+          dp.ns8[c][g] = nullspace[dp.ns_off[d] + j * dp.G + g];
+      }
   }
   return DDD_OK;
 }
@@ -267,7 +264,7 @@ void decide_mfma(ddd_model* m) {
   char why[256] = "";
   bool ok = true;
   auto no = [&](const char* msg) { if (ok) snprintf(why, sizeof(why), "%s", msg); ok = false; };
-  if (dp.N < 8 || dp.N > ddd::mfma::kRows) no("num_points outside [8, 256]");
+  if (dp.N < 8 || dp.N > 256) no("num_points outside [8, 256]");
   if (dp.G > ddd::kGMax) no("stencil wider than 8");
   if (!dp.fixed) {
     if (dp.target != ddd::TARGET_COEFFICIENTS) no("model_target is not 'coefficients'");
@@ -311,13 +308,25 @@ int check_batch(const ddd_model* m, int batch) {
   return DDD_OK;
 }
 
+// Rows per workgroup of the MFMA path: one free-running wavefront per
+// workgroup when whole samples fit 64 rows, else 256 rows with block barriers.
+int mfma_rows(const ddd_model* m) {
+  if (m->force_rows == 64 || m->force_rows == 256) return m->force_rows;
+  return (m->dp.N <= 64 && 64 % m->dp.N == 0) ? 64 : 256;
+}
+
 int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
   if (a.batch == 0) return DDD_OK;
   if (m->kernel == DDD_KERNEL_MFMA) {
-    const int spg = ddd::mfma::kRows / m->dp.N;
+    const int rows = mfma_rows(m);
+    const int spg = rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
-    hipLaunchKernelGGL(ddd::mfma::substep_kernel, dim3(blocks), dim3(256), 0, stream,
-                       m->dp, a);
+    if (rows == 64)
+      hipLaunchKernelGGL(ddd::mfma::substep_kernel<64>, dim3(blocks), dim3(64), 0, stream,
+                         m->dp, a);
+    else
+      hipLaunchKernelGGL(ddd::mfma::substep_kernel<256>, dim3(blocks), dim3(256), 0,
+                         stream, m->dp, a);
   } else {
     int rc = check_generic_lds(m, 0);
     if (rc) return rc;
@@ -331,19 +340,33 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   return DDD_OK;
 }
 
+template <int kRows, typename ST>
+void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
+  const int spg = kRows / m->dp.N;
+  const int blocks = (a.batch + spg - 1) / spg;
+  const bool hoist = !m->dp.fixed && m->dp.L == 3;
+  if (hoist)
+    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, ST, true>), dim3(blocks),
+                       dim3(kRows), 0, stream, m->dp, a);
+  else
+    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, ST, false>), dim3(blocks),
+                       dim3(kRows), 0, stream, m->dp, a);
+}
+
 template <typename ST>
-int launch_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
+int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
+  {
+    const char* env = std::getenv("DDD_PRIO_SPLIT");   // A/B switch, default off
+    a.prio_split = env != nullptr ? std::atoi(env) : 0;
+    const char* stg = std::getenv("DDD_STAGGER");
+    a.stagger = stg != nullptr ? std::atoi(stg) : 0;
+    const char* abl = std::getenv("DDD_ABLATE");   // profiling only: WRONG RESULTS
+    a.ablate = abl != nullptr ? std::atoi(abl) : 0;
+  }
   if (m->kernel == DDD_KERNEL_MFMA) {
-    const int spg = ddd::mfma::kRows / m->dp.N;
-    const int blocks = (a.batch + spg - 1) / spg;
-    const bool hoist = !m->dp.fixed && m->dp.L == 3;
-    if (hoist)
-      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<ST, true>), dim3(blocks), dim3(256),
-                         0, stream, m->dp, a);
-    else
-      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<ST, false>), dim3(blocks), dim3(256),
-                         0, stream, m->dp, a);
+    if (mfma_rows(m) == 64) launch_mfma_integrate<64, ST>(m, a, stream);
+    else launch_mfma_integrate<256, ST>(m, a, stream);
   } else {
     int rc = check_generic_lds(m, (int)sizeof(ST));
     if (rc) return rc;
@@ -527,9 +550,9 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
 int ddd_model_destroy(ddd_model* m) {
   if (m == nullptr) return DDD_OK;
   free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
-  free_dev(m->d_nullspace8); free_dev(m->d_bias8); free_dev(m->d_w_hidden);
+  free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp);
+  free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   free_dev(m->d_scratch);
   delete m;
   return DDD_OK;
@@ -537,8 +560,9 @@ int ddd_model_destroy(ddd_model* m) {
 
 int ddd_clear_forcing(ddd_model* m) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
-  free_dev(m->d_frc); free_dev(m->d_sp);
-  m->d_frc = nullptr; m->d_sp = nullptr;
+  free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  m->d_frc = nullptr; m->d_sp = nullptr; m->d_trig = nullptr;
+  m->dp.trig = nullptr;
   m->dp.forced = 0; m->dp.P = 0; m->dp.n_k = 0; m->dp.forcing_batch = 0;
   m->dp.frc = nullptr; m->dp.sp = nullptr;
   return DDD_OK;
@@ -556,20 +580,42 @@ int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude
   if (rc) return rc;
   if (!is_forced_family(m->cfg.equation)) return DDD_OK;   // finalize is the identity
   const size_t count = (size_t)batch * nparams;
-  std::vector<float4> packed(count);
-  for (size_t i = 0; i < count; ++i) {
+  for (size_t i = 0; i < count; ++i)
     if (k_index[i] < 0 || k_index[i] >= n_k)
       return fail(DDD_ERR_INVALID_ARGUMENT, "k_index[%zu] = %d outside [0, %d)", i,
                   k_index[i], n_k);
-    float kbits;
-    const int32_t ki = k_index[i];
-    std::memcpy(&kbits, &ki, sizeof(kbits));
-    packed[i] = make_float4(amplitude[i], omega[i], phase[i], kbits);
+  // Each sample's modes are stored sorted by k_index (stable), so that the
+  // kernels sum the modes sharing a wavenumber over a contiguous range.
+  std::vector<float4> packed(count);
+  std::vector<int> order(nparams);
+  for (int b = 0; b < batch; ++b) {
+    const size_t base = (size_t)b * nparams;
+    for (int j = 0; j < nparams; ++j) order[j] = j;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+      return k_index[base + x] < k_index[base + y];
+    });
+    for (int j = 0; j < nparams; ++j) {
+      const size_t i = base + order[j];
+      float kbits;
+      const int32_t ki = k_index[i];
+      std::memcpy(&kbits, &ki, sizeof(kbits));
+      packed[base + j] = make_float4(amplitude[i], omega[i], phase[i], kbits);
+    }
   }
   std::vector<float> sp(spatial_phase, spatial_phase + (size_t)n_k * m->dp.N);
+  // cos / sin of the (float32) spatial phase per grid point, [N][n_k][2]
+  std::vector<float> trig((size_t)m->dp.N * n_k * 2);
+  for (int x = 0; x < m->dp.N; ++x)
+    for (int k = 0; k < n_k; ++k) {
+      const double theta = (double)sp[(size_t)k * m->dp.N + x];
+      trig[((size_t)x * n_k + k) * 2 + 0] = (float)std::cos(theta);
+      trig[((size_t)x * n_k + k) * 2 + 1] = (float)std::sin(theta);
+    }
   rc = upload(packed, &m->d_frc);
   if (!rc) rc = upload(sp, &m->d_sp);
+  if (!rc) rc = upload(trig, &m->d_trig);
   if (rc) return rc;
+  m->dp.trig = m->d_trig;
   m->dp.frc = m->d_frc;
   m->dp.sp = m->d_sp;
   m->dp.forced = 1;
@@ -753,15 +799,23 @@ int ddd_set_kernel(ddd_model* m, int kind) {
   switch (kind) {
     case DDD_KERNEL_AUTO:
       m->kernel = m->mfma_ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;
+      m->force_rows = 0;
       return DDD_OK;
     case DDD_KERNEL_GENERIC:
       m->kernel = DDD_KERNEL_GENERIC;
       return DDD_OK;
     case DDD_KERNEL_MFMA:
+    case DDD_KERNEL_MFMA_ROWS64:
+    case DDD_KERNEL_MFMA_ROWS256:
       if (!m->mfma_ok)
         return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
                     m->mfma_reason.c_str());
+      if (kind == DDD_KERNEL_MFMA_ROWS64 && !(m->dp.N <= 64 && 64 % m->dp.N == 0))
+        return fail(DDD_ERR_UNSUPPORTED,
+                    "64-row workgroups need num_points to divide 64 (got %d)", m->dp.N);
       m->kernel = DDD_KERNEL_MFMA;
+      m->force_rows = kind == DDD_KERNEL_MFMA_ROWS64 ? 64
+                      : kind == DDD_KERNEL_MFMA_ROWS256 ? 256 : 0;
       return DDD_OK;
     default:
       return fail(DDD_ERR_INVALID_ARGUMENT, "unknown kernel kind %d", kind);
@@ -770,10 +824,21 @@ int ddd_set_kernel(ddd_model* m, int kind) {
 
 const char* ddd_kernel_name(const ddd_model* m) {
   if (m == nullptr) return "";
-  return m->kernel == DDD_KERNEL_MFMA ? "mfma_f32" : "generic";
+  if (m->kernel != DDD_KERNEL_MFMA) return "generic";
+  return mfma_rows(m) == 64 ? "mfma_f32_r64" : "mfma_f32_r256";
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
+
+int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
+  unsigned* d = nullptr;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d), (size_t)blocks * 4 * sizeof(unsigned)));
+  hipLaunchKernelGGL(ddd::ops::hwid_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d, spin);
+  DDD_HIP(hipGetLastError());
+  DDD_HIP(hipMemcpy(out_host, d, (size_t)blocks * 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return DDD_OK;
+}
 
 int ddd_selftest_mfma_layout(void) {
   float* d32 = nullptr;

@@ -35,9 +35,15 @@ struct DevParams {
   const float* weights;    // natural layout, layer-major (kernel then bias)
   const float* nullspace;  // per derivative [in_size][G]
   const float* bias;       // [D][G]  (accuracy-layer bias, or fixed stencils)
-  const float* nullspace8; // same, rows zero-padded to 8 columns (MFMA path)
-  const float* bias8;      // [D][8]
-  int ns8_off[kMaxDerivs];
+  // MFMA-path projection tables, carried in the kernel-argument segment so
+  // that rows arrive as scalar (SGPR) operands: for output channel c of the
+  // conv tower, ns8[c] is its null-space row zero-padded to 8 stencil columns
+  // and dsel the derivative it feeds; bias8[d] likewise.
+  float ns8[16][kGMax];
+  float bias8[kMaxDerivs][kGMax];
+  // dsel packed: 2 bits per channel (derivative index) + validity mask, so the
+  // hot loop tests one scalar register instead of indexing a 16-SGPR tuple.
+  unsigned dsel_bits, dsel_valid;
   const float* w_input;    // MFMA-packed input layer, 3 x 64
   const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
   const float* w_final;    // MFMA-packed output layer, 41 x 64
@@ -45,6 +51,7 @@ struct DevParams {
   int forced, P, n_k, forcing_batch;
   const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)
   const float* sp;         // [n_k][N]   spatial phase table
+  const float* trig;       // [N][n_k][2] cos / sin of the spatial phase
 };
 
 // Explicit RK tableau in "previous-stage only" form:
@@ -63,6 +70,9 @@ struct IntegrateArgs {
   const void* y0;   // [batch][N] StateT
   void* y_out;      // [n_saved][batch][N] StateT
   int batch;
+  int prio_split;   // 1: odd hardware wave slots run at raised priority
+  int ablate;       // profiling only (DDD_ABLATE): bit mask of phases to skip
+  int stagger;      // profiling only (DDD_STAGGER): initial s_sleep count for odd waves
 };
 
 struct SubstepArgs {

@@ -113,5 +113,22 @@ __global__ void mfma_layout_probe_kernel(float* __restrict__ out32,
   }
 }
 
+// Debug: record the hardware placement of each single-wave workgroup
+// (HW_REG_HW_ID and XCC_ID) under the same LDS footprint as the 64-row kernel.
+__global__ __launch_bounds__(64) void hwid_probe_kernel(unsigned* __restrict__ out, int spin) {
+  __shared__ float pad[5088];   // 20352 B, as Shared<64>
+  pad[threadIdx.x] = (float)blockIdx.x;
+  unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_ID, 32 bits
+  unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+  float acc = pad[threadIdx.x];
+  for (int i = 0; i < spin; ++i) acc = acc * 1.0001f + 0.5f;       // keep waves resident
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 4 + 0] = hw;
+    out[blockIdx.x * 4 + 1] = xcc;
+    out[blockIdx.x * 4 + 2] = (unsigned)__builtin_amdgcn_s_memtime();
+    out[blockIdx.x * 4 + 3] = __float_as_uint(acc);
+  }
+}
+
 }  // namespace ops
 }  // namespace ddd

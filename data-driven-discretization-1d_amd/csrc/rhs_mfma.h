@@ -1,8 +1,10 @@
 // Fused learned-stencil right-hand side + Runge-Kutta stepping on CDNA4 f32 MFMA.
 //
 // Work decomposition (DESIGN.md "MFMA kernel"):
-//   * one workgroup = 256 "rows" (grid points) = floor(256 / N) whole samples,
-//     4 wavefronts, wavefront w owns rows [64 w, 64 w + 64);
+//   * one workgroup = kRows "rows" (grid points) = floor(kRows / N) whole
+//     samples; wavefront w owns rows [64 w, 64 w + 64).  kRows = 64 (one
+//     free-running wavefront per workgroup) when samples fit a wavefront
+//     (64 % N == 0), else 256 (four wavefronts, block barriers between layers);
 //   * the conv tower runs on the matrix cores as implicit GEMMs
 //         D[out-channel][position] += W[out-channel][k] * h[k][position],
 //     reduction index k = (tap, in-channel):
@@ -27,29 +29,38 @@
 namespace ddd {
 namespace mfma {
 
-constexpr int kRows = 256;       // rows per workgroup
 constexpr int kHS = 36;          // padded activation row stride (floats)
 constexpr int kF = 32;           // hidden channels
 constexpr int kKW = 5;           // conv taps
 constexpr int kInSteps = 3;      // (5 taps + bias) / 2
 constexpr int kHidSteps = 81;    // 5*32/2 MFMA steps + 1 bias step
 constexpr int kFinSteps = 41;    // 5*32/4 MFMA steps + 1 bias step
-constexpr int kFrcLds = 256;     // forcing entries (samples*modes) staged in LDS
-constexpr int kTabRows = 4 + 16; // bias8 rows + nullspace8 rows
+constexpr int kTrigMax = 12;     // 2 * (distinct wavenumbers) kept per lane
+constexpr int kTabRows = 4 + 16; // bias8 rows + one null-space row per output channel
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// kRows = rows (grid points) per workgroup: 256 (four wavefronts, block
+// barriers between layers) or 64 (ONE wavefront owns whole samples, N <= 64:
+// no cross-wave dependency, wavefronts free-run and eight workgroups share a
+// CU).  Sizes are chosen so that 160 KiB of LDS hold 2 x 256-row or 8 x 64-row
+// workgroups.
+template <int kRows>
 struct Shared {
+  static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
+  static constexpr int kFkMax = 3 * kRows / 4;  // samples * n_k * 2 harmonic sums
   float hA[kRows * kHS];
   float hB[kRows * kHS];
   float u[kRows];
-  float un[kRows];                // u / standard_deviation
   float flux[kRows];
-  float4 frc[kFrcLds];
-  float tab[kTabRows * kGMax];    // [0,4): bias8[d][8]; [4,20): nullspace8 rows
+  float2 pm[kPmMax];              // per (sample, mode): a sin(psi), a cos(psi)
+  float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
+  unsigned char ks[kRows];        // per sample: start of each k's run of modes, [8]
+  float tab[kTabRows * kGMax];    // [0,4): bias8[d][8]; [4,20): ns8 rows per channel
 };
-static_assert(sizeof(Shared) <= 80 * 1024, "two workgroups must fit one CU's LDS");
+static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
+static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
 
 // Value the optimiser must treat as unknown: stops loop-invariant code motion
 // from hoisting per-evaluation index math and loads out of the time loop (where
@@ -77,6 +88,7 @@ __device__ __forceinline__ int row_sample(int row, float inv_n) {
   return (int)(((float)row + 0.5f) * inv_n);
 }
 
+template <int kRows>
 __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid) {
   Lane ln;
   ln.row = tid;
@@ -127,8 +139,11 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
   if (act == ACT_RELU) {
+    // one v_med3_f32 per element: med3(x, 0, +inf) == max(x, 0) for every
+    // non-NaN x (fmaxf would cost an extra canonicalising v_max)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = fmaxf(acc[r], 0.0f);
+    for (int r = 0; r < 16; ++r)
+      acc[r] = __builtin_amdgcn_fmed3f(acc[r], 0.0f, __builtin_inff());
   } else if (act == ACT_RELU6) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
@@ -157,21 +172,21 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 
 // Input layer 1 -> 32 for this wave's two 32-row tiles (3 MFMA steps each).
 //   A: lane l supplies W1[out = l & 31][k = 2 s + (l >> 5)]  (k = tap; k = 5: bias)
-//   B: lane l supplies un[(pos(l & 31) + k - 2) mod N]        (k = 5: 1.0)
+//   B: lane l supplies u[(pos(l & 31) + k - 2) mod N] / std   (k = 5: 1.0)
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
-                                            const float* __restrict__ un,
-                                            float* __restrict__ out) {
+                                            const float* __restrict__ us,
+                                            float* __restrict__ out,
+                                            const float (&w)[kInSteps]) {
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  float w[kInSteps];
-#pragma unroll
-  for (int s = 0; s < kInSteps; ++s) w[s] = p.w_input[s * 64 + ln.lane];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int trow = ln.wave * 64 + t * 32 + j;
-    const float b0 = un[tile_src_row(ln, trow, half - 2, p.N)];        // taps 0 / 1
-    const float b1 = un[tile_src_row(ln, trow, half, p.N)];            // taps 2 / 3
-    const float b2 = half ? 1.0f : un[tile_src_row(ln, trow, 2, p.N)]; // tap 4 / bias
+    // net = inputs / standard_deviation (model.py:450-451), a true division
+    const float b0 = us[tile_src_row(ln, trow, half - 2, p.N)] / p.stddev;   // taps 0 / 1
+    const float b1 = us[tile_src_row(ln, trow, half, p.N)] / p.stddev;       // taps 2 / 3
+    const float b2 = half ? 1.0f                                            // bias row
+                          : us[tile_src_row(ln, trow, 2, p.N)] / p.stddev;   // tap 4
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -192,11 +207,13 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
 __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
-                                             const float (&w)[kHidSteps]) {
+                                             const float (&w)[kHidSteps],
+                                             bool prio_ramp = false) {
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
+    if (prio_ramp) { if (t == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
     const int trow = ln.wave * 64 + t * 32 + j;
     const float4* rowp[kKW];
 #pragma unroll
@@ -232,23 +249,27 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
 //   B: lane l supplies h[k = 4 s + (l >> 4)][position = l & 15]
 //   step s = 8 tap + jj, quarter = l >> 4  <->  (tap, cin = 8 quarter + jj)
 //   D: lane l holds position l & 15, out-channel 4 (l >> 4) + r.
-// The 41 weight values are streamed from L2 tap by tap (8 live registers), not
-// kept resident: with the hidden layer's 81 resident registers that keeps the
-// kernel inside 256 VGPRs (2 waves / SIMD).
+// Its 41 weight registers are loaded by the caller BEFORE the hidden layers run
+// (the L2 latency hides behind their MFMAs) and die with this function.
+__device__ __forceinline__ void load_final(const DevParams& p, int lane,
+                                           float (&w)[kFinSteps]) {
+  const float* src = p.w_final + lane;
+#pragma unroll
+  for (int s = 0; s < kFinSteps; ++s) w[s] = src[s * 64];
+}
+
 __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ in,
-                                            float* __restrict__ out) {
+                                            float* __restrict__ out,
+                                            const float (&wf)[kFinSteps]) {
   const int j = ln.lane & 15;
   const int quarter = ln.lane >> 4;
-  const float* __restrict__ wsrc = p.w_final + ln.lane;
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int tap = 0; tap < kKW; ++tap) {
-    float w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = wsrc[(tap * 8 + i) * 64];
+    const float* w = wf + tap * 8;
     float4 v0[4], v1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -273,7 +294,7 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
       acc[t] = DDD_MFMA16(w[7], v1[t].w, acc[t]);
     }
   }
-  const float wb = wsrc[40 * 64];
+  const float wb = wf[40];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
@@ -283,22 +304,58 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
   }
 }
 
+// Kernel-lifetime registers of one lane: hoisted once per launch.
+struct Resident {
+  float w_in[kInSteps];     // input-layer weights (MFMA A operand)
+  float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
+};
+
 // One evaluation of finalize_time_derivative(t, predict_time_derivative(u))
-// for the workgroup's rows.  Must be called by all 256 threads.
+// for the workgroup's rows.  Must be called by all kRows threads.
 //   model.predict_coefficients  model.py:420-513   (conv tower + projection)
 //   model.apply_coefficients    model.py:536-548   (stencil apply)
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
-// kHoist: wts_hid already holds the (single) hidden layer's weights.
-template <bool kHoist>
-__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared& sm, int batch,
-                                          float u, float t,
-                                          float (&wts_hid)[kHidSteps], bool frc_in_lds,
-                                          float* derivs_out, float* coeffs_out) {
-  const Lane ln = make_lane(p, batch, opaque((int)threadIdx.x));
+// kHoist: res.hid already holds the (single) hidden layer's weights.
+template <int kRows, bool kHoist>
+__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm, int batch,
+                                          float u, float t, Resident& res,
+                                          bool fast_forcing, float* derivs_out,
+                                          float* coeffs_out, int ablate = 0) {
+  const Lane ln = make_lane<kRows>(p, batch, opaque((int)threadIdx.x));
   sm.u[ln.row] = u;
-  if (!p.fixed) sm.un[ln.row] = u / p.stddev;   // model.py:450-451
+  const int spg = kRows / p.N;
+  if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.P) {
+    // forcing, phase 1: one (sample, mode) pair per lane.
+    //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
+    //     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
+    //   psi_j = omega_j t + phi_j,  theta_j(x) = 2 pi k_j x / L  (<= 6 distinct k)
+    const int fsl = row_sample(ln.row, 1.0f / (float)p.P);   // row / P, exact
+    const long sample = (long)blockIdx.x * spg + fsl;
+    float2 v = make_float2(0.0f, 0.0f);
+    if (sample < batch) {
+      const float4 q = p.frc[sample * p.P + (ln.row - fsl * p.P)];
+      float sn, cs;
+      sincosf(q.y * t + q.z, &sn, &cs);
+      v = make_float2(q.x * sn, q.x * cs);
+    }
+    sm.pm[ln.row] = v;
+  }
   __syncthreads();
+  if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.n_k * 2) {
+    // phase 2: per (sample, k, sin|cos) sum over the modes carrying that k.
+    // Modes are stored sorted by k (ddd_set_forcing), so the run is contiguous.
+    const int which = ln.row & 1;
+    const int sl = row_sample(ln.row >> 1, 1.0f / (float)p.n_k);   // exact
+    const int kk = (ln.row >> 1) - sl * p.n_k;
+    const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
+    float acc = 0.0f;
+    for (int m = m0; m < m1; ++m) {
+      const float2 v = sm.pm[sl * p.P + m];
+      acc = acc + (which ? v.y : v.x);
+    }
+    sm.fk[ln.row] = acc;
+  }
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
   float pch[kGMax];
@@ -307,21 +364,41 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared& sm, int ba
   for (int g = 0; g < kGMax; ++g)
     pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
 
-  const float* net = nullptr;
+  // this grid point's cos / sin of the spatial phases: issued now, used last
+  float trig[kTrigMax];
+  if (p.forced && fast_forcing) {
+    const float* __restrict__ tr = p.trig + (size_t)opaque(ln.pos) * p.n_k * 2;
+#pragma unroll
+    for (int i = 0; i < kTrigMax; ++i) trig[i] = (i < 2 * p.n_k) ? tr[i] : 0.0f;
+  }
+
+  float net[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) net[c] = 0.0f;
   if (!p.fixed) {
-    input_layer(p, ln, sm.un, sm.hA);
+    float wfin[kFinSteps];
+    if (!(ablate & 16)) input_layer(p, ln, sm.u, sm.hA, res.w_in);
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < p.L - 1; ++l) {
-      if (!kHoist) load_hidden(p, l - 1, ln.lane, wts_hid);
+      if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
       __syncthreads();
-      hidden_layer(p, ln, in, out, wts_hid);
+      if (!(ablate & 8)) hidden_layer(p, ln, in, out, res.hid, (ablate & 32) != 0);
       float* tmp = in; in = out; out = tmp;
     }
+    load_final(p, opaque(ln.lane), wfin);
     __syncthreads();
-    final_layer(p, ln, in, out);
+    if (ablate & 32) __builtin_amdgcn_s_setprio(3);
+    if (!(ablate & 4)) final_layer(p, ln, in, out, wfin);
+    if (ablate & 32) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
-    net = out + ln.row * kHS;
+    const float4* nrow = reinterpret_cast<const float4*>(out + ln.row * kHS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = nrow[q];
+      net[4 * q + 0] = v.x; net[4 * q + 1] = v.y;
+      net[4 * q + 2] = v.z; net[4 * q + 3] = v.w;
+    }
   } else {
     __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
   }
@@ -329,37 +406,54 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared& sm, int ba
   // ---- projection onto the accuracy-constrained stencils + stencil apply -----
   // coeff = bias + net[start:stop] @ nullspace   (polynomials.py:275-277)
   // deriv = sum_i coeff[i] * patch[i]            (model.py:548)
+  // Output channel c feeds derivative dsel(c) (wave-uniform kernel argument)
+  // with the null-space row staged in LDS at tab[4 + c]: per channel one
+  // uniform branch, two broadcast ds_read_b128 at compile-time offsets and 8
+  // FMAs -- no dependent address chain.
+  float cf[kMaxDerivs][kGMax];
+#pragma unroll
+  for (int d = 0; d < kMaxDerivs; ++d)
+#pragma unroll
+    for (int g = 0; g < kGMax; ++g) cf[d][g] = 0.0f;
+  if (!p.fixed && !(ablate & 2)) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (!((p.dsel_valid >> c) & 1u)) continue;
+      const unsigned d = (p.dsel_bits >> (2 * c)) & 3u;
+      const float nv = net[c];
+      const float4 n0 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax);
+      const float4 n1 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax + 4);
+      const float nsr[kGMax] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      if (d == 0) {
+#pragma unroll
+        for (int g = 0; g < kGMax; ++g) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
+      } else if (d == 1) {
+#pragma unroll
+        for (int g = 0; g < kGMax; ++g) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
+      } else if (d == 2) {
+#pragma unroll
+        for (int g = 0; g < kGMax; ++g) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
+      } else {
+#pragma unroll
+        for (int g = 0; g < kGMax; ++g) cf[3][g] = fmaf(nv, nsr[g], cf[3][g]);
+      }
+    }
+  }
   float dv[kMaxDerivs];
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d) {
     dv[d] = 0.0f;
     if (d < p.D) {
-      float coeff[kGMax];
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) coeff[g] = 0.0f;
-      if (!p.fixed) {
-        const float* __restrict__ ns = sm.tab + (4 + p.in_start[d]) * kGMax;
-        for (int jx = 0; jx < p.in_size[d]; ++jx) {
-          const float nv = net[p.in_start[d] + jx];
-          const float4 n0 = *reinterpret_cast<const float4*>(ns + jx * kGMax);
-          const float4 n1 = *reinterpret_cast<const float4*>(ns + jx * kGMax + 4);
-          coeff[0] = fmaf(nv, n0.x, coeff[0]); coeff[1] = fmaf(nv, n0.y, coeff[1]);
-          coeff[2] = fmaf(nv, n0.z, coeff[2]); coeff[3] = fmaf(nv, n0.w, coeff[3]);
-          coeff[4] = fmaf(nv, n1.x, coeff[4]); coeff[5] = fmaf(nv, n1.y, coeff[5]);
-          coeff[6] = fmaf(nv, n1.z, coeff[6]); coeff[7] = fmaf(nv, n1.w, coeff[7]);
-        }
-      }
-      const float* __restrict__ b8 = sm.tab + d * kGMax;
-#pragma unroll
-      for (int g = 0; g < kGMax; ++g) coeff[g] = b8[g] + coeff[g];
+      for (int g = 0; g < kGMax; ++g) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
       if (coeffs_out != nullptr && ln.active) {
         float* dst = coeffs_out + ((size_t)ln.gidx * p.D + d) * p.G;
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (g < p.G) dst[g] = coeff[g];
+        for (int g = 0; g < kGMax; ++g) if (g < p.G) dst[g] = cf[d][g];
       }
       float s = 0.0f;
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) s = fmaf(coeff[g], pch[g], s);
+      for (int g = 0; g < kGMax; ++g) s = fmaf(cf[d][g], pch[g], s);
       dv[d] = s;
     }
   }
@@ -377,16 +471,14 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared& sm, int ba
     const float fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
   }
-  if (p.forced) {
-    if (frc_in_lds) {
+  if (p.forced && !(ablate & 1)) {
+    if (fast_forcing) {
+      // phase 3: combine with this grid point's cos / sin table
+      const float* __restrict__ fk = sm.fk + ln.sl * p.n_k * 2;
       float total = 0.0f;
-      const float4* frc = sm.frc + ln.sl * p.P;
-      for (int m = 0; m < p.P; ++m) {
-        const float4 q = frc[m];
-        const float sp = p.sp[__float_as_int(q.w) * p.N + ln.pos];
-        const float phase = (q.y * t + sp) + q.z;
-        total = total + q.x * sinf(phase);
-      }
+#pragma unroll
+      for (int i = 0; i < kTrigMax; ++i)
+        if (i < 2 * p.n_k) total = fmaf(fk[i], trig[i], total);
       r = r + total;
     } else if (ln.active) {
       r = r + forcing_at(p, p.frc + (size_t)(ln.gidx / p.N) * p.P, ln.pos, t);
@@ -395,43 +487,53 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared& sm, int ba
   return r;
 }
 
-// Per-launch staging of the small read-only tables into LDS.
-__device__ __forceinline__ bool stage_tables(const DevParams& p, Shared& sm, int batch) {
+// Per-launch setup: resident registers and the per-sample tables in LDS.
+template <int kRows, bool kHoist>
+__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& sm,
+                                             const Lane& ln, int batch, Resident& res) {
   const int tid = threadIdx.x;
-  if (tid < kTabRows * kGMax) {
-    float v = 0.0f;
-    const int rowi = tid / kGMax, g = tid % kGMax;
-    if (rowi < 4) {
-      if (rowi < p.D) v = p.bias8[rowi * kGMax + g];
-    } else if (!p.fixed && rowi - 4 < p.C_out) {
-      v = p.nullspace8[(rowi - 4) * kGMax + g];
-    }
-    sm.tab[tid] = v;
-  }
   const int spg = kRows / p.N;
-  const bool fits = p.forced && (spg * p.P <= kFrcLds);
-  if (fits) {
-    for (int i = tid; i < spg * p.P; i += blockDim.x) {
-      const long sample = (long)blockIdx.x * spg + i / p.P;
-      sm.frc[i] = sample < batch ? p.frc[sample * p.P + (i % p.P)]
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = tid; i < kTabRows * kGMax; i += kRows) {
+    const int rowi = i / kGMax, g = i % kGMax;
+    sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
+  }
+  const bool fast = p.forced && spg * p.P <= Shared<kRows>::kPmMax && p.n_k <= 6 &&
+                    spg * p.n_k * 2 <= Shared<kRows>::kFkMax && p.P < 256;
+#pragma unroll
+  for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
+  if (!p.fixed) {
+#pragma unroll
+    for (int s = 0; s < kInSteps; ++s) res.w_in[s] = p.w_input[s * 64 + ln.lane];
+    if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
+  }
+  if (fast) {
+    // ks[sl][kk] = first mode of sample sl whose k index is >= kk (modes sorted)
+    if (tid < spg) {
+      const long sample = (long)blockIdx.x * spg + tid;
+      int m = 0;
+      for (int kk = 0; kk < 8; ++kk) {
+        if (sample < batch)
+          while (m < p.P && __float_as_int(p.frc[sample * p.P + m].w) < kk) ++m;
+        sm.ks[tid * 8 + kk] = (unsigned char)m;
+      }
     }
   }
-  return fits;   // visibility: the first __syncthreads() of eval_rhs
+  return fast;   // visibility of sm.ks: the first __syncthreads() of eval_rhs
 }
 
 // ---------------------------------------------------------------------------
 // Kernel 1: one fused RK substep (also: plain time derivative, derivative and
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void substep_kernel(DevParams p, SubstepArgs a) {
-  __shared__ Shared sm;
-  const Lane ln = make_lane(p, a.batch, threadIdx.x);
-  const bool frc_lds = stage_tables(p, sm, a.batch);
-  float wts_hid[kHidSteps];
+template <int kRows>
+__global__ __launch_bounds__(kRows, 2) void substep_kernel(DevParams p, SubstepArgs a) {
+  __shared__ Shared<kRows> sm;
+  const Lane ln = make_lane<kRows>(p, a.batch, threadIdx.x);
+  Resident res;
+  const bool fast_frc = launch_setup<kRows, false>(p, sm, ln, a.batch, res);
   const float u = ln.active ? a.y_in[ln.gidx] : 0.0f;
-  const float f = eval_rhs<false>(p, sm, a.batch, u, (float)a.t, wts_hid, frc_lds,
-                                  a.derivs_out, a.coeffs_out);
+  const float f = eval_rhs<kRows, false>(p, sm, a.batch, u, (float)a.t, res, fast_frc,
+                                         a.derivs_out, a.coeffs_out);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
     const float cf = a.c1 * f;
@@ -448,13 +550,30 @@ __global__ __launch_bounds__(256, 2) void substep_kernel(DevParams p, SubstepArg
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-template <typename ST, bool kHoist>
-__global__ __launch_bounds__(256, 2) void integrate_kernel(DevParams p, IntegrateArgs a) {
-  __shared__ Shared sm;
-  const Lane ln = make_lane(p, a.batch, threadIdx.x);
-  const bool frc_lds = stage_tables(p, sm, a.batch);
-  float wts_hid[kHidSteps];
-  if (kHoist) load_hidden(p, 0, ln.lane, wts_hid);
+template <int kRows, typename ST, bool kHoist>
+__global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, IntegrateArgs a) {
+  __shared__ Shared<kRows> sm;
+  const Lane ln = make_lane<kRows>(p, a.batch, threadIdx.x);
+  Resident res;
+  const bool fast_frc = launch_setup<kRows, kHoist>(p, sm, ln, a.batch, res);
+  // Two wavefronts share each SIMD and run the same phases; left alone they
+  // phase-lock (both in their MFMA phase, then both in their VALU phase, the
+  // matrix pipe idling).  A static priority split by hardware wave slot lets
+  // one of them win every arbitration, which de-synchronises the pair so one
+  // wave's VALU / LDS phases overlap the other's MFMA phases
+  // (MI355X_MICROARCH.md "Two waves per SIMD", item 4).
+  int ablate = a.ablate & 0xff;
+  if ((a.ablate >> 8) != 0 &&
+      ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) != 0))
+    ablate = (a.ablate >> 8) & 0xff;   // DDD_ABLATE high byte: mask for odd wave slots
+  if (a.prio_split) {   // A/B experiments (DDD_PRIO_SPLIT / DDD_STAGGER), off by default
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xfu;   // HW_ID.wave_id
+    const bool odd = (a.prio_split & 2) ? ((blockIdx.x >> 10) & 1u) != 0 : (wave_slot & 1u) != 0;
+    if (odd) {
+      if (a.prio_split & 4) __builtin_amdgcn_s_setprio(3);
+      for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
   const ST* y0 = static_cast<const ST*>(a.y0);
   ST* y_out = static_cast<ST*>(a.y_out);
   ST y = ln.active ? y0[ln.gidx] : (ST)0;
@@ -469,9 +588,9 @@ __global__ __launch_bounds__(256, 2) void integrate_kernel(DevParams p, Integrat
     for (int s = 0; s < a.tab.stages; ++s) {
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
-      const float f = eval_rhs<kHoist>(p, sm, a.batch, (float)us,
-                                       (float)(t + a.tab.c[s] * a.dt), wts_hid,
-                                       frc_lds, nullptr, nullptr);
+      const float f = eval_rhs<kRows, kHoist>(p, sm, a.batch, (float)us,
+                                              (float)(t + a.tab.c[s] * a.dt), res,
+                                              fast_frc, nullptr, nullptr, ablate);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
     }

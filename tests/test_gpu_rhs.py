@@ -51,14 +51,14 @@ def _check_all_views(model, y0, t, forcing, tol):
   return err
 
 
-@pytest.mark.parametrize('kernel', ['mfma', 'generic'])
+@pytest.mark.parametrize('kernel', ['mfma64', 'mfma256', 'generic'])
 @pytest.mark.parametrize('equation,conservative,numerical_flux', ALL_EQUATIONS)
 def test_time_derivative_all_equations(equation, conservative, numerical_flux,
                                        kernel):
   model = make_model(equation, conservative, numerical_flux, num_points=64,
                      resample_factor=4, seed=3)
   model.set_kernel(kernel)
-  assert model.kernel_name == ('mfma_f32' if kernel == 'mfma' else 'generic')
+  assert model.kernel_name.startswith('mfma_f32' if kernel != 'generic' else 'generic')
   batch = 7    # not a multiple of the 4 samples per workgroup
   y0 = random_phase_ic(model.equation, batch)
   forcing = batch_forcing(batch, seed0=50)
@@ -73,7 +73,7 @@ def test_time_derivative_all_equations(equation, conservative, numerical_flux,
 def test_grid_sizes_mfma(num_points, batch):
   """Rows per workgroup = floor(256 / N) samples, incl. non-power-of-two N."""
   model = make_model('burgers', True, num_points=num_points, resample_factor=2)
-  assert model.kernel_name == 'mfma_f32'
+  assert model.kernel_name.startswith('mfma_f32')
   y0 = random_phase_ic(model.equation, batch)
   forcing = batch_forcing(batch)
   model.set_forcing(forcing)
@@ -89,7 +89,7 @@ def test_grid_sizes_mfma(num_points, batch):
 ])
 def test_network_variants_mfma(overrides):
   model = make_model('burgers', False, num_points=64, **overrides)
-  assert model.kernel_name == 'mfma_f32', overrides
+  assert model.kernel_name.startswith('mfma_f32'), overrides
   y0 = random_phase_ic(model.equation, 5)
   forcing = batch_forcing(5)
   model.set_forcing(forcing)
@@ -239,3 +239,24 @@ def test_conservation_large_batch():
   y0 = random_phase_ic(model.equation, batch)
   got = model.time_derivative(y0, 0.0).cpu().numpy().astype(np.float64)
   assert np.abs(got.sum(axis=1)).max() < 1e-3 * np.abs(got).max()
+
+
+def test_rows_per_workgroup_selection():
+  """One free-running wavefront per workgroup when N divides 64, else 256 rows."""
+  for n, name in [(64, 'mfma_f32_r64'), (32, 'mfma_f32_r64'), (16, 'mfma_f32_r64'),
+                  (48, 'mfma_f32_r256'), (128, 'mfma_f32_r256'),
+                  (256, 'mfma_f32_r256')]:
+    model = make_model('kdv', False, num_points=n, resample_factor=1)
+    assert model.kernel_name == name, (n, model.kernel_name)
+  model = make_model('kdv', False, num_points=48, resample_factor=1)
+  with pytest.raises(Exception, match='divide 64'):
+    model.set_kernel('mfma64')
+  model = make_model('burgers', True, num_points=32)
+  y0 = random_phase_ic(model.equation, 11)
+  forcing = batch_forcing(11)
+  model.set_forcing(forcing)
+  a = model.time_derivative(y0, 0.4).cpu().numpy()
+  model.set_kernel('mfma256')
+  assert model.kernel_name == 'mfma_f32_r256'
+  b = model.time_derivative(y0, 0.4).cpu().numpy()
+  np.testing.assert_array_equal(a, b)    # same arithmetic, different tiling
