@@ -72,8 +72,8 @@ def build_workload(args, rank):
     model = model_lib.LearnedStencilModel(eq, hp, init_seed=0, output_scale=0.1)
   model.set_kernel(args.kernel)
   # sample ids are global: rank r owns ids [r*batch, (r+1)*batch)
-  first = rank * args.batch
-  seeds = range(first, first + args.batch)
+  from ddd1d_amd import distributed
+  seeds = distributed.weak_shard_ids(args.batch, rank)
   forcing = model_lib.batched_forcing_parameters(seeds, nparams=20)
   model.set_forcing(forcing)
   ic = model_lib.batched_forcing_parameters(
@@ -87,34 +87,35 @@ def build_workload(args, rank):
 
 
 def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
-  """Time the CPU port (oracle) on a bounded sample of the same workload."""
+  """Time the CPU port (oracle/ddd_oracle.c, OpenMP over samples) on a bounded
+  sample of the same workload: same model, scheme and per-sample forcing."""
   sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-  import oracle   # the timed baseline leg; never the product
+  import c_oracle   # the timed baseline leg; never the product
+  import oracle
   scheme_id = {'euler': oracle.SCHEME_EULER, 'midpoint': oracle.SCHEME_MIDPOINT,
                'bs3': oracle.SCHEME_BS3, 'rk4': oracle.SCHEME_RK4}[scheme]
-  spec = model.spec()
-  sample = min(64, y0.shape[0])
+  co = c_oracle.COracle(model.spec(), nparams=forcing['a'].shape[1])
+  threads = co.num_threads
+  sample = min(y0.shape[0], max(threads, 64))
+  sample -= sample % threads if sample >= threads else 0
   frc = {k: v[:sample] for k, v in forcing.items()}
   ys = y0[:sample]
   t0 = time.perf_counter()
-  oracle.integrate_fixed(spec, scheme_id, 0.0, dt, 1, 1, ys, forcing=frc)
+  co.integrate_fixed(scheme_id, 0.0, dt, 1, ys, frc)
   one = time.perf_counter() - t0
-  steps = int(max(1, min(200, budget_s / max(one, 1e-6))))
+  steps = int(max(2, min(2000, budget_s / max(one, 1e-6))))
   t0 = time.perf_counter()
-  oracle.integrate_fixed(spec, scheme_id, 0.0, dt, steps, steps, ys, forcing=frc)
+  co.integrate_fixed(scheme_id, 0.0, dt, steps, ys, frc)
   elapsed = time.perf_counter() - t0
   points = sample * ys.shape[1] * steps
-  try:
-    import threadpoolctl
-    threads = max([p['num_threads'] for p in threadpoolctl.threadpool_info()] or [1])
-  except Exception:  # pylint: disable=broad-except
-    threads = 1
   return {
       'value': points / elapsed, 'unit': 'grid-point-steps/s', 'cores': threads,
       'kind': 'port',
-      'sample': 'NumPy float32 restatement (oracle/oracle.py), same model and '
-                'scheme, batch {} x {} steps, {:.1f} s; host has {} logical cores'
-                .format(sample, steps, elapsed, os.cpu_count()),
+      'sample': 'C/OpenMP float32 restatement of the reference path '
+                '(oracle/ddd_oracle.c: conv tower, projection, stencil apply, '
+                'forcing on the reference grid, same RK scheme), batch {} x {} '
+                'steps in {:.1f} s on {} threads; host has {} logical cores'
+                .format(sample, steps, elapsed, threads, os.cpu_count()),
   }
 
 

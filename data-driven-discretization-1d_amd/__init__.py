@@ -13,6 +13,7 @@ from . import _lib
 from . import layers
 from . import model
 from . import integrate
+from . import distributed
 from .hparams import HParams, create_hparams, load_hparams, save_hparams
 
 __version__ = '0.1.0'

@@ -113,15 +113,33 @@ class _DeviceModel(object):
   """Owns a ``ddd_model*`` and exposes the batched kernel entry points."""
 
   def __init__(self):
-    self._handle = None
+    self._handle_ = None
     self.equation = None
     self._forcing = None   # dict of float64 arrays (for spec())
+    self._kernel_kind = 'auto'
+
+  # The device handle is created on first use, so weights can be built, saved
+  # and loaded on a host without a GPU; every kernel entry point needs one.
+  @property
+  def _handle(self):
+    if self._handle_ is None:
+      self._create_handle()
+      if self._kernel_kind != 'auto':
+        _lib.check(_lib.load_library().ddd_set_kernel(
+            self._handle_, _lib.KERNELS[self._kernel_kind]))
+      if self._forcing is not None:
+        self._upload_forcing(self._forcing)
+    return self._handle_
+
+  @_handle.setter
+  def _handle(self, value):
+    self._handle_ = value
 
   # -- lifecycle -------------------------------------------------------------
   def close(self):
-    if self._handle is not None and _lib._lib is not None:
-      _lib._lib.ddd_model_destroy(self._handle)
-    self._handle = None
+    if self._handle_ is not None and _lib._lib is not None:
+      _lib._lib.ddd_model_destroy(self._handle_)
+    self._handle_ = None
 
   def __del__(self):
     try:
@@ -153,6 +171,7 @@ class _DeviceModel(object):
   def set_kernel(self, kind: str):
     _lib.check(_lib.load_library().ddd_set_kernel(self._handle,
                                                   _lib.KERNELS[kind]))
+    self._kernel_kind = kind
 
   @property
   def fma_per_point(self) -> int:
@@ -170,11 +189,21 @@ class _DeviceModel(object):
     finalize_time_derivative (equations.py:276-277); for the others the tables
     are accepted and ignored, as in the reference.
     """
-    lib = _lib.load_library()
     if forcing is None:
-      _lib.check(lib.ddd_clear_forcing(self._handle))
       self._forcing = None
+      if self._handle_ is not None:
+        _lib.check(_lib.load_library().ddd_clear_forcing(self._handle_))
       return
+    forcing = {k: np.asarray(v) for k, v in forcing.items()}
+    shapes = {np.shape(forcing[k]) for k in ('a', 'omega', 'k', 'phi')}
+    if len(shapes) != 1 or len(next(iter(shapes))) != 2:
+      raise ValueError('forcing arrays must share one [batch, nparams] shape')
+    self._forcing = forcing
+    if self._handle_ is not None:
+      self._upload_forcing(forcing)
+
+  def _upload_forcing(self, forcing):
+    lib = _lib.load_library()
     tables = forcing_kernel_tables(forcing, self.equation.grid)
     batch, nparams = tables['amplitude'].shape
     amp = np.ascontiguousarray(tables['amplitude'])
@@ -183,10 +212,9 @@ class _DeviceModel(object):
     kidx = np.ascontiguousarray(tables['k_index'])
     spatial = np.ascontiguousarray(tables['spatial_phase'])
     _lib.check(lib.ddd_set_forcing(
-        self._handle, batch, nparams, _lib.fptr(amp), _lib.fptr(omega),
+        self._handle_, batch, nparams, _lib.fptr(amp), _lib.fptr(omega),
         _lib.fptr(phase), kidx.ctypes.data_as(_lib._I), _lib.fptr(spatial),
         spatial.shape[0]))
-    self._forcing = {k: np.asarray(v) for k, v in forcing.items()}
 
   def set_forcing_from_equation(self, batch: int = 1):
     """Use this model's own equation.forcing for every sample (B copies)."""
@@ -373,7 +401,6 @@ class LearnedStencilModel(_DeviceModel):
       self.constant_coefficients = (
           np.zeros(c_out, np.float32) if constant_coefficients is None
           else np.asarray(constant_coefficients, dtype=np.float32))
-    self._create_handle()
 
   @staticmethod
   def synthetic_weights(layer_shapes, seed=0, output_scale=0.1):
@@ -533,11 +560,13 @@ class BaselineModel(_DeviceModel):
       table[d, shift:shift + len(taps)] = taps.astype(np.float32)
     self.stencil_size = width
     self.table = table
+
+  def _create_handle(self):
     lib = _lib.load_library()
     _lib.require_gpu()
-    cfg = self._base_config(equation, width)
+    cfg = self._base_config(self.equation, self.stencil_size)
     handle = ctypes.c_void_p()
-    flat = _lib.host_f32(table)
+    flat = _lib.host_f32(self.table)
     _lib.check(lib.ddd_baseline_create(ctypes.byref(cfg), _lib.fptr(flat),
                                        flat.size, ctypes.byref(handle)))
     self._handle = handle
