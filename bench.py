@@ -100,13 +100,14 @@ def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
   sample -= sample % threads if sample >= threads else 0
   frc = {k: v[:sample] for k, v in forcing.items()}
   ys = y0[:sample]
-  t0 = time.perf_counter()
-  co.integrate_fixed(scheme_id, 0.0, dt, 1, ys, frc)
-  one = time.perf_counter() - t0
-  steps = int(max(2, min(2000, budget_s / max(one, 1e-6))))
-  t0 = time.perf_counter()
-  co.integrate_fixed(scheme_id, 0.0, dt, steps, ys, frc)
-  elapsed = time.perf_counter() - t0
+  co.integrate_fixed(scheme_id, 0.0, dt, 2, ys, frc)    # thread pool warm-up
+  steps, elapsed, chunk, state = 0, 0.0, 8, ys
+  while elapsed < budget_s and steps < 200000:
+    t0 = time.perf_counter()
+    state = co.integrate_fixed(scheme_id, steps * dt, dt, chunk, state, frc)
+    elapsed += time.perf_counter() - t0
+    steps += chunk
+    chunk = min(chunk * 2, 4096)
   points = sample * ys.shape[1] * steps
   return {
       'value': points / elapsed, 'unit': 'grid-point-steps/s', 'cores': threads,
