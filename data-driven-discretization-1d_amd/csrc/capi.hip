@@ -237,9 +237,43 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
   }
   {
     const int l = dp.L - 1;
-    const int cout_n = dp.C_out;
-    const float* w = weights + dp.w_off[l];   // [5][32][C_out]
-    const float* b = weights + dp.b_off[l];
+    const float* w_nat = weights + dp.w_off[l];   // [5][32][C_out]
+    const float* b_nat = weights + dp.b_off[l];
+    int cout_n = dp.C_out;
+    std::vector<float> wf, bf;
+    const float* w = w_nat;
+    const float* b = b_nat;
+    m->dp.folded = 0;
+    const char* nofold = std::getenv("DDD_NO_FOLD");
+    if (dp.D <= 2 && !(nofold != nullptr && nofold[0] == '1')) {
+      // Fold coeff_delta = net[start:stop] @ nullspace into the output layer:
+      // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
+      // (accumulated in double, rounded once to float32), same for the bias.
+      // The layer then emits the D x 8 coefficient deltas directly and the
+      // epilogue's projection disappears.  Deviation from the reference's
+      // operation order: O(1 ulp) of the deltas, far inside the 1e-5 tolerance.
+      cout_n = 16;
+      wf.assign((size_t)5 * 32 * 16, 0.0f);
+      bf.assign(16, 0.0f);
+      for (int d = 0; d < dp.D; ++d)
+        for (int g = 0; g < dp.G; ++g) {
+          const int oc = 8 * d + g;
+          for (int tc = 0; tc < 5 * 32; ++tc) {
+            double acc = 0.0;
+            for (int j = 0; j < dp.in_size[d]; ++j)
+              acc += (double)w_nat[(size_t)tc * dp.C_out + dp.in_start[d] + j] *
+                     (double)dp.ns8[dp.in_start[d] + j][g];
+            wf[(size_t)tc * 16 + oc] = (float)acc;
+          }
+          double acc = 0.0;
+          for (int j = 0; j < dp.in_size[d]; ++j)
+            acc += (double)b_nat[dp.in_start[d] + j] * (double)dp.ns8[dp.in_start[d] + j][g];
+          bf[oc] = (float)acc;
+        }
+      w = wf.data();
+      b = bf.data();
+      m->dp.folded = 1;
+    }
     std::vector<float> packed((size_t)ddd::mfma::kFinSteps * 64, 0.0f);
     for (int s = 0; s < 40; ++s) {
       const int tap = s / 8, jj = s % 8;
@@ -361,6 +395,9 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
     a.prio_split = env != nullptr ? std::atoi(env) : 0;
     const char* stg = std::getenv("DDD_STAGGER");
     a.stagger = stg != nullptr ? std::atoi(stg) : 0;
+    const char* trc = std::getenv("DDD_TRACE_PTR");   // profiling only: device buffer address
+    a.trace = trc != nullptr ? reinterpret_cast<unsigned long long*>(std::strtoull(trc, nullptr, 0))
+                             : nullptr;
     const char* abl = std::getenv("DDD_ABLATE");   // profiling only: WRONG RESULTS
     a.ablate = abl != nullptr ? std::atoi(abl) : 0;
   }
@@ -837,6 +874,34 @@ int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
   DDD_HIP(hipGetLastError());
   DDD_HIP(hipMemcpy(out_host, d, (size_t)blocks * 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
   (void)hipFree(d);
+  return DDD_OK;
+}
+
+int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* ticks_per_mfma,
+                        double* wall_ns_per_mfma) {
+  unsigned long long* d = nullptr;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d), (size_t)blocks * 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  DDD_HIP(hipEventCreate(&e0));
+  DDD_HIP(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    DDD_HIP(hipEventRecord(e0, nullptr));
+#define DDD_RATE(C, W) hipLaunchKernelGGL((ddd::ops::mfma_rate_probe_kernel<C, W>), dim3(blocks), dim3(64), 0, nullptr, d, iters, 1.0f)
+    if (is32) { if (chains == 1) DDD_RATE(1, true); else if (chains == 2) DDD_RATE(2, true); else DDD_RATE(4, true); }
+    else { if (chains == 1) DDD_RATE(1, false); else if (chains == 2) DDD_RATE(2, false); else DDD_RATE(4, false); }
+#undef DDD_RATE
+    DDD_HIP(hipEventRecord(e1, nullptr));
+    DDD_HIP(hipEventSynchronize(e1));
+  }
+  float ms = 0.0f;
+  DDD_HIP(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h((size_t)blocks * 2);
+  DDD_HIP(hipMemcpy(h.data(), d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  double sum = 0.0;
+  for (int b = 0; b < blocks; ++b) sum += (double)h[(size_t)b * 2];
+  *ticks_per_mfma = sum / blocks / ((double)iters * 8.0);
+  *wall_ns_per_mfma = (double)ms * 1e6 / ((double)iters * 8.0);
   return DDD_OK;
 }
 

@@ -9,6 +9,7 @@ constexpr int kMaxDerivs = 4;
 constexpr int kMaxLayers = 8;
 constexpr int kMaxStages = 4;
 constexpr int kGMax = 8;      // widest stencil the MFMA path handles
+constexpr int kTraceSlots = 256;
 constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
 
 // Equation ids: include/ddd1d.h enum ddd_equation.
@@ -44,6 +45,10 @@ struct DevParams {
   // dsel packed: 2 bits per channel (derivative index) + validity mask, so the
   // hot loop tests one scalar register instead of indexing a 16-SGPR tuple.
   unsigned dsel_bits, dsel_valid;
+  // folded = 1: the output layer's packed weights already contain the
+  // null-space projection (W3 @ nullspace), so output channel 8 d + g IS the
+  // coefficient delta of derivative d, stencil column g (D <= 2 only).
+  int folded;
   const float* w_input;    // MFMA-packed input layer, 3 x 64
   const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
   const float* w_final;    // MFMA-packed output layer, 41 x 64
@@ -73,6 +78,7 @@ struct IntegrateArgs {
   int prio_split;   // 1: odd hardware wave slots run at raised priority
   int ablate;       // profiling only (DDD_ABLATE): bit mask of phases to skip
   int stagger;      // profiling only (DDD_STAGGER): initial s_sleep count for odd waves
+  unsigned long long* trace;   // profiling only: [blocks][kTraceSlots] s_memtime stamps
 };
 
 struct SubstepArgs {
@@ -98,6 +104,29 @@ __device__ __forceinline__ float apply_activation(float x, int act) {
     case ACT_ELU: return x > 0.0f ? x : expm1f(x);
     default: return x;
   }
+}
+
+// Branch-free sin and cos of a float32 angle (|x| < ~1e5): three-term
+// Cody-Waite reduction by pi/2 with FMAs, then the classic single-precision
+// minimax polynomials on [-pi/4, pi/4].  Max error ~1e-7 absolute: below the
+// float32 rounding of the phase itself (ulp(25)/2 = 1e-6).
+__device__ __forceinline__ void sincos_branchless(float x, float* s, float* c) {
+  const float j = rintf(x * 0.63661977236758134f);   // x * 2/pi
+  float r = fmaf(-j, 1.5703125f, x);
+  r = fmaf(-j, 4.837512969970703125e-4f, r);
+  r = fmaf(-j, 7.54978995489188216e-8f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float sr = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float cr = fmaf(r2 * r2, pc, fmaf(r2, -0.5f, 1.0f));
+  const int q = (int)j;
+  const float s0 = (q & 1) ? cr : sr;
+  const float c0 = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -s0 : s0;
+  *c = ((q + 1) & 2) ? -c0 : c0;
 }
 
 // Godunov flux for u^2/2 (equations.py:341-349).

@@ -130,5 +130,36 @@ __global__ __launch_bounds__(64) void hwid_probe_kernel(unsigned* __restrict__ o
   }
 }
 
+// Debug: matrix-pipe rate probe.  Each wave issues `iters` x 8 MFMAs in
+// `chains` (1, 2 or 4) independent accumulator chains and reports s_memtime
+// ticks, so ticks per MFMA can be compared with the nominal 64 / 32 cycles.
+template <int kChains, bool k32>
+__global__ __launch_bounds__(64) void mfma_rate_probe_kernel(unsigned long long* out,
+                                                              int iters, float seed) {
+  f32x16 a32[4];
+  f32x4 a16[4];
+  for (int c = 0; c < 4; ++c) {
+    for (int r = 0; r < 16; ++r) a32[c][r] = seed * (float)(c + r);
+    for (int r = 0; r < 4; ++r) a16[c][r] = seed * (float)(c + r);
+  }
+  const float x = seed + threadIdx.x, y = seed * 0.5f - threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = k % kChains;
+      if (k32) a32[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a32[c], 0, 0, 0);
+      else a16[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a16[c], 0, 0, 0);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float sink = 0.0f;
+  for (int c = 0; c < 4; ++c) sink += a32[c][0] + a16[c][0];
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 2 + 0] = t1 - t0;
+    out[blockIdx.x * 2 + 1] = (unsigned long long)__float_as_uint(sink);
+  }
+}
+
 }  // namespace ops
 }  // namespace ddd

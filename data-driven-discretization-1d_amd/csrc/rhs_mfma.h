@@ -35,6 +35,8 @@ constexpr int kKW = 5;           // conv taps
 constexpr int kInSteps = 3;      // (5 taps + bias) / 2
 constexpr int kHidSteps = 81;    // 5*32/2 MFMA steps + 1 bias step
 constexpr int kFinSteps = 41;    // 5*32/4 MFMA steps + 1 bias step
+constexpr int kFinPrefetch = 0;  // output-layer weight registers fetched before the hidden layers
+                                 // (A/B on MI355X: 8 made the output layer ~1000 cycles slower)
 constexpr int kTrigMax = 12;     // 2 * (distinct wavenumbers) kept per lane
 constexpr int kTabRows = 4 + 16; // bias8 rows + one null-space row per output channel
 
@@ -53,7 +55,8 @@ struct Shared {
   float hA[kRows * kHS];
   float hB[kRows * kHS];
   float u[kRows];
-  float flux[kRows];
+  float un[kRows];                // u / standard_deviation (input-layer operand)
+  float flux[kRows == 64 ? 1 : kRows];   // 64-row groups exchange flux by shuffle
   float2 pm[kPmMax];              // per (sample, mode): a sin(psi), a cos(psi)
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
   unsigned char ks[kRows];        // per sample: start of each k's run of modes, [8]
@@ -172,29 +175,30 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 
 // Input layer 1 -> 32 for this wave's two 32-row tiles (3 MFMA steps each).
 //   A: lane l supplies W1[out = l & 31][k = 2 s + (l >> 5)]  (k = tap; k = 5: bias)
-//   B: lane l supplies u[(pos(l & 31) + k - 2) mod N] / std   (k = 5: 1.0)
+//   B: lane l supplies un[(pos(l & 31) + k - 2) mod N], un = u / std   (k = 5: 1.0)
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ us,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps]) {
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
+  f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int trow = ln.wave * 64 + t * 32 + j;
-    // net = inputs / standard_deviation (model.py:450-451), a true division
-    const float b0 = us[tile_src_row(ln, trow, half - 2, p.N)] / p.stddev;   // taps 0 / 1
-    const float b1 = us[tile_src_row(ln, trow, half, p.N)] / p.stddev;       // taps 2 / 3
-    const float b2 = half ? 1.0f                                            // bias row
-                          : us[tile_src_row(ln, trow, 2, p.N)] / p.stddev;   // tap 4
-    f32x16 acc;
+    const float b0 = us[tile_src_row(ln, trow, half - 2, p.N)];        // taps 0 / 1
+    const float b1 = us[tile_src_row(ln, trow, half, p.N)];            // taps 2 / 3
+    const float b2 = half ? 1.0f : us[tile_src_row(ln, trow, 2, p.N)]; // bias row / tap 4
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    acc = DDD_MFMA32(w[0], b0, acc);
-    acc = DDD_MFMA32(w[1], b1, acc);
-    acc = DDD_MFMA32(w[2], b2, acc);
-    activate16(acc, p.act);
-    store_tile32(out, trow, half, acc);
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    acc[t] = DDD_MFMA32(w[0], b0, acc[t]);
+    acc[t] = DDD_MFMA32(w[1], b1, acc[t]);
+    acc[t] = DDD_MFMA32(w[2], b2, acc[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    activate16(acc[t], p.act);
+    store_tile32(out, ln.wave * 64 + t * 32 + j, half, acc[t]);
   }
 }
 
@@ -209,39 +213,56 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
                                              bool prio_ramp = false) {
+  (void)prio_ramp;
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
+  // The wave's two 32-row tiles advance together: a dependent 32x32x2 chain
+  // issues only every ~85 cycles (measured), two independent accumulators keep
+  // the 64-cycle matrix pipe full, and each weight register feeds both tiles.
+  const int trow0 = ln.wave * 64 + j;
+  const int trow1 = trow0 + 32;
+  const float4* rowp0[kKW];
+  const float4* rowp1[kKW];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (prio_ramp) { if (t == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); }
-    const int trow = ln.wave * 64 + t * 32 + j;
-    const float4* rowp[kKW];
-#pragma unroll
-    for (int tap = 0; tap < kKW; ++tap)
-      rowp[tap] = reinterpret_cast<const float4*>(
-          in + tile_src_row(ln, trow, tap - 2, p.N) * kHS + 16 * half);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    float4 cur = rowp[0][0];
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the read of group 0
-#pragma unroll
-    for (int g = 0; g < 20; ++g) {
-      float4 nxt = cur;
-      if (g + 1 < 20) nxt = rowp[(g + 1) >> 2][(g + 1) & 3];
-      acc = DDD_MFMA32(w[4 * g + 0], cur.x, acc);
-      acc = DDD_MFMA32(w[4 * g + 1], cur.y, acc);
-      acc = DDD_MFMA32(w[4 * g + 2], cur.z, acc);
-      acc = DDD_MFMA32(w[4 * g + 3], cur.w, acc);
-      cur = nxt;
-      // keep "read group g+1, then the 4 MFMAs of group g" in the schedule
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // 4 MFMA
-    }
-    acc = DDD_MFMA32(w[80], 1.0f, acc);   // bias row: k = 160 carries b[out]
-    activate16(acc, p.act);
-    store_tile32(out, trow, half, acc);
+  for (int tap = 0; tap < kKW; ++tap) {
+    rowp0[tap] = reinterpret_cast<const float4*>(
+        in + tile_src_row(ln, trow0, tap - 2, p.N) * kHS + 16 * half);
+    rowp1[tap] = reinterpret_cast<const float4*>(
+        in + tile_src_row(ln, trow1, tap - 2, p.N) * kHS + 16 * half);
   }
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+  float4 cur0 = rowp0[0][0];
+  float4 cur1 = rowp1[0][0];
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the reads of group 0
+#pragma unroll
+  for (int g = 0; g < 20; ++g) {
+    float4 nxt0 = cur0, nxt1 = cur1;
+    if (g + 1 < 20) {
+      nxt0 = rowp0[(g + 1) >> 2][(g + 1) & 3];
+      nxt1 = rowp1[(g + 1) >> 2][(g + 1) & 3];
+    }
+    acc0 = DDD_MFMA32(w[4 * g + 0], cur0.x, acc0);
+    acc1 = DDD_MFMA32(w[4 * g + 0], cur1.x, acc1);
+    acc0 = DDD_MFMA32(w[4 * g + 1], cur0.y, acc0);
+    acc1 = DDD_MFMA32(w[4 * g + 1], cur1.y, acc1);
+    acc0 = DDD_MFMA32(w[4 * g + 2], cur0.z, acc0);
+    acc1 = DDD_MFMA32(w[4 * g + 2], cur1.z, acc1);
+    acc0 = DDD_MFMA32(w[4 * g + 3], cur0.w, acc0);
+    acc1 = DDD_MFMA32(w[4 * g + 3], cur1.w, acc1);
+    cur0 = nxt0;
+    cur1 = nxt1;
+    // keep "read group g+1 of both tiles, then the 8 MFMAs of group g"
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+  }
+  acc0 = DDD_MFMA32(w[80], 1.0f, acc0);   // bias row: k = 160 carries b[out]
+  acc1 = DDD_MFMA32(w[80], 1.0f, acc1);
+  activate16(acc0, p.act);
+  activate16(acc1, p.act);
+  store_tile32(out, trow0, half, acc0);
+  store_tile32(out, trow1, half, acc1);
 }
 
 // Output layer (32 -> C_out <= 16, linear) for this wave's four 16-row tiles.
@@ -308,6 +329,7 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
 struct Resident {
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
+  float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
 };
 
 // One evaluation of finalize_time_derivative(t, predict_time_derivative(u))
@@ -321,24 +343,22 @@ template <int kRows, bool kHoist>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm, int batch,
                                           float u, float t, Resident& res,
                                           bool fast_forcing, float* derivs_out,
-                                          float* coeffs_out, int ablate = 0) {
+                                          float* coeffs_out, int ablate = 0,
+                                          unsigned long long* trace = nullptr) {
+#define DDD_STAMP(i) do { if (trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  DDD_STAMP(0);
   const Lane ln = make_lane<kRows>(p, batch, opaque((int)threadIdx.x));
   sm.u[ln.row] = u;
+  if (!p.fixed) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
   const int spg = kRows / p.N;
   if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.P) {
     // forcing, phase 1: one (sample, mode) pair per lane.
     //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
     //     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
     //   psi_j = omega_j t + phi_j,  theta_j(x) = 2 pi k_j x / L  (<= 6 distinct k)
-    const int fsl = row_sample(ln.row, 1.0f / (float)p.P);   // row / P, exact
-    const long sample = (long)blockIdx.x * spg + fsl;
-    float2 v = make_float2(0.0f, 0.0f);
-    if (sample < batch) {
-      const float4 q = p.frc[sample * p.P + (ln.row - fsl * p.P)];
-      float sn, cs;
-      sincosf(q.y * t + q.z, &sn, &cs);
-      v = make_float2(q.x * sn, q.x * cs);
-    }
+    float sn, cs;
+    sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
+    const float2 v = make_float2(res.frc_a * sn, res.frc_a * cs);
     sm.pm[ln.row] = v;
   }
   __syncthreads();
@@ -377,7 +397,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   for (int c = 0; c < 16; ++c) net[c] = 0.0f;
   if (!p.fixed) {
     float wfin[kFinSteps];
-    if (!(ablate & 16)) input_layer(p, ln, sm.u, sm.hA, res.w_in);
+    DDD_STAMP(1);
+    if (!(ablate & 16)) input_layer(p, ln, sm.un, sm.hA, res.w_in);
+    {   // first taps of the output layer: in flight while the hidden layers run
+      const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
+#pragma unroll
+      for (int s2 = 0; s2 < kFinPrefetch; ++s2) wfin[s2] = wsrc[s2 * 64];
+    }
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < p.L - 1; ++l) {
@@ -386,11 +412,17 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
       if (!(ablate & 8)) hidden_layer(p, ln, in, out, res.hid, (ablate & 32) != 0);
       float* tmp = in; in = out; out = tmp;
     }
-    load_final(p, opaque(ln.lane), wfin);
+    DDD_STAMP(2);
+    {
+      const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
+#pragma unroll
+      for (int s2 = kFinPrefetch; s2 < kFinSteps; ++s2) wfin[s2] = wsrc[s2 * 64];
+    }
     __syncthreads();
     if (ablate & 32) __builtin_amdgcn_s_setprio(3);
     if (!(ablate & 4)) final_layer(p, ln, in, out, wfin);
     if (ablate & 32) __builtin_amdgcn_s_setprio(0);
+    DDD_STAMP(3);
     __syncthreads();
     const float4* nrow = reinterpret_cast<const float4*>(out + ln.row * kHS);
 #pragma unroll
@@ -415,7 +447,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   for (int d = 0; d < kMaxDerivs; ++d)
 #pragma unroll
     for (int g = 0; g < kGMax; ++g) cf[d][g] = 0.0f;
-  if (!p.fixed && !(ablate & 2)) {
+  if (!p.fixed && p.folded) {
+    // the output layer already applied the projection: channel 8 d + g
+#pragma unroll
+    for (int g = 0; g < kGMax; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
+  } else if (!p.fixed && !(ablate & 2)) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (!((p.dsel_valid >> c) & 1u)) continue;
@@ -466,9 +502,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   // ---- equation of motion ------------------------------------------------------
   float r = equation_rhs_or_flux(p.equation, u, dv, p.eta);
   if (p.conservative) {
-    sm.flux[ln.row] = r;
-    __syncthreads();
-    const float fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
+    float fnext;
+    if (kRows == 64) {
+      // whole samples live in this wavefront: the right neighbour's flux comes
+      // straight from its lane
+      fnext = __shfl(r, wrap_row(ln.base, ln.pos, 1, p.N), 64);
+    } else {
+      sm.flux[ln.row] = r;
+      __syncthreads();
+      fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
+    }
     r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
   }
   if (p.forced && !(ablate & 1)) {
@@ -484,6 +527,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
       r = r + forcing_at(p, p.frc + (size_t)(ln.gidx / p.N) * p.P, ln.pos, t);
     }
   }
+  DDD_STAMP(4);
+#undef DDD_STAMP
   return r;
 }
 
@@ -505,6 +550,15 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& 
 #pragma unroll
     for (int s = 0; s < kInSteps; ++s) res.w_in[s] = p.w_input[s * 64 + ln.lane];
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
+  }
+  res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
+  if (fast && tid < spg * p.P) {
+    const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
+    const long sample = (long)blockIdx.x * spg + fsl;
+    if (sample < batch) {
+      const float4 q = p.frc[sample * p.P + (tid - fsl * p.P)];
+      res.frc_a = q.x; res.frc_omega = q.y; res.frc_phi = q.z;
+    }
   }
   if (fast) {
     // ks[sl][kk] = first mode of sample sl whose k index is >= kk (modes sorted)
@@ -581,6 +635,7 @@ __global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, Integr
   const size_t snap_stride = (size_t)a.batch * p.N;
   int until_save = a.save_every;
   size_t snap = 0;
+  int evals = 0;
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
     ST ynew = y;
@@ -588,9 +643,13 @@ __global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, Integr
     for (int s = 0; s < a.tab.stages; ++s) {
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
+      unsigned long long* tr = nullptr;
+      if (a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
+        tr = a.trace + (size_t)blockIdx.x * kTraceSlots + evals * 5;
+      ++evals;
       const float f = eval_rhs<kRows, kHoist>(p, sm, a.batch, (float)us,
                                               (float)(t + a.tab.c[s] * a.dt), res,
-                                              fast_frc, nullptr, nullptr, ablate);
+                                              fast_frc, nullptr, nullptr, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
     }

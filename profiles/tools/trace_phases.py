@@ -1,0 +1,34 @@
+import os, sys, json, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import ddd1d_amd
+from ddd1d_amd import equations, model as model_lib
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}))
+_, eq = equations.from_hparams(hp)
+m = model_lib.LearnedStencilModel(eq, hp)
+m.set_forcing(model_lib.batched_forcing_parameters(range(B), nparams=20))
+y0 = torch.randn(B, 64, device='cuda') * 0.3
+trace = torch.zeros(B * 256, dtype=torch.int64, device='cuda')
+os.environ['DDD_TRACE_PTR'] = str(trace.data_ptr())
+m.integrate_fixed(y0, 25, dt=1e-3, save_every=25)
+torch.cuda.synchronize()
+tr = trace.cpu().numpy().reshape(B, 256)[:, :250].reshape(B, 50, 5)
+# co-resident pairs (from the placement probe): block b and b + 768 (first round)
+for b in (0, 1, 8):
+    for partner in (b + 768, b + 1024):
+        if partner >= B: continue
+        a0 = tr[b, :, 0]; p0 = tr[partner, :, 0]
+        print('block', b, 'partner', partner)
+        print('  eval period A', np.diff(a0)[:12])
+        print('  eval period P', np.diff(p0)[:12])
+        print('  start offset P-A per eval', (p0 - a0)[:12])
+        print('  A phases (input,hidden,final,epilogue):', (tr[b, 5:9, 1:] - tr[b, 5:9, :4]).tolist())
+np.save('gpurun_out/trace.npy', tr)
+names = ['u/frc(0-1)', 'input+hidden(1-2)', 'final(2-3)', 'epilogue(3-4)', 'loop(4-0)']
+d = np.diff(tr[:, 5:45, :].astype(np.int64), axis=2)            # [B, 40, 4]
+loop = tr[:, 6:46, 0].astype(np.int64) - tr[:, 5:45, 4].astype(np.int64)
+allp = np.concatenate([d, loop[..., None]], axis=2)
+print('B =', B, 'mean cycles per phase over waves/evals:')
+for i, n in enumerate(names):
+    print('  %-20s mean %8.0f  median %8.0f  min %8.0f' % (n, allp[..., i].mean(), np.median(allp[..., i]), allp[..., i].min()))
+print('  period mean', np.diff(tr[:, 5:45, 0].astype(np.int64), axis=1).mean())
