@@ -640,13 +640,14 @@ int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude
     }
   }
   std::vector<float> sp(spatial_phase, spatial_phase + (size_t)n_k * m->dp.N);
-  // cos / sin of the (float32) spatial phase per grid point, [N][n_k][2]
-  std::vector<float> trig((size_t)m->dp.N * n_k * 2);
+  // cos / sin of the (float32) spatial phase per grid point, [N][12] zero
+  // padded (entry 2 k = cos, 2 k + 1 = sin of phase table row k; n_k <= 6)
+  std::vector<float> trig((size_t)m->dp.N * 12, 0.0f);
   for (int x = 0; x < m->dp.N; ++x)
-    for (int k = 0; k < n_k; ++k) {
+    for (int k = 0; k < n_k && k < 6; ++k) {
       const double theta = (double)sp[(size_t)k * m->dp.N + x];
-      trig[((size_t)x * n_k + k) * 2 + 0] = (float)std::cos(theta);
-      trig[((size_t)x * n_k + k) * 2 + 1] = (float)std::sin(theta);
+      trig[(size_t)x * 12 + 2 * k + 0] = (float)std::cos(theta);
+      trig[(size_t)x * 12 + 2 * k + 1] = (float)std::sin(theta);
     }
   rc = upload(packed, &m->d_frc);
   if (!rc) rc = upload(sp, &m->d_sp);

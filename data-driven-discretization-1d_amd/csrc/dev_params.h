@@ -56,7 +56,7 @@ struct DevParams {
   int forced, P, n_k, forcing_batch;
   const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)
   const float* sp;         // [n_k][N]   spatial phase table
-  const float* trig;       // [N][n_k][2] cos / sin of the spatial phase
+  const float* trig;       // [N][12] cos / sin of the spatial phases, zero padded
 };
 
 // Explicit RK tableau in "previous-stage only" form:

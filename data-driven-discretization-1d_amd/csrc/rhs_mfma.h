@@ -51,7 +51,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int kRows>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
-  static constexpr int kFkMax = 3 * kRows / 4;  // samples * n_k * 2 harmonic sums
+  static constexpr int kFkMax = 3 * kRows / 4;  // samples * 12 harmonic sums (zero padded)
   float hA[kRows * kHS];
   float hB[kRows * kHS];
   float u[kRows];
@@ -130,6 +130,25 @@ __device__ __forceinline__ int tile_src_row(const Lane& ln, int trow, int off, i
   return trow < ln.rows_used ? src : trow;
 }
 
+// Rows of grid points (pos - 2 .. pos + 2) mod N for tile row `trow`: the five
+// conv taps.  One sample lookup per tile row, then one compare/select per tap
+// (the sign of each offset is known at compile time).
+__device__ __forceinline__ void tap_rows(const Lane& ln, int trow, int n,
+                                         int (&rows)[kKW]) {
+  const int base = row_sample(trow, ln.inv_n) * n;
+  const int pos = trow - base;
+  int qm2 = pos - 2; qm2 = qm2 < 0 ? qm2 + n : qm2;
+  int qm1 = pos - 1; qm1 = qm1 < 0 ? qm1 + n : qm1;
+  int qp1 = pos + 1; qp1 = qp1 >= n ? qp1 - n : qp1;
+  int qp2 = pos + 2; qp2 = qp2 >= n ? qp2 - n : qp2;
+  const bool live = trow < ln.rows_used;   // spare rows read themselves
+  rows[0] = live ? base + qm2 : trow;
+  rows[1] = live ? base + qm1 : trow;
+  rows[2] = trow;
+  rows[3] = live ? base + qp1 : trow;
+  rows[4] = live ? base + qp2 : trow;
+}
+
 __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index,
                                             int lane, float (&w)[kHidSteps]) {
   const float* src = p.w_hidden + (size_t)hidden_index * kHidSteps * 64 + lane;
@@ -179,16 +198,16 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ us,
                                             float* __restrict__ out,
-                                            const float (&w)[kInSteps]) {
+                                            const float (&w)[kInSteps],
+                                            const int (&rows)[2][kKW]) {
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
   f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int trow = ln.wave * 64 + t * 32 + j;
-    const float b0 = us[tile_src_row(ln, trow, half - 2, p.N)];        // taps 0 / 1
-    const float b1 = us[tile_src_row(ln, trow, half, p.N)];            // taps 2 / 3
-    const float b2 = half ? 1.0f : us[tile_src_row(ln, trow, 2, p.N)]; // bias row / tap 4
+    const float b0 = us[half ? rows[t][1] : rows[t][0]];        // taps 0 / 1
+    const float b1 = us[half ? rows[t][3] : rows[t][2]];        // taps 2 / 3
+    const float b2 = half ? 1.0f : us[rows[t][4]];              // tap 4 / bias row
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     acc[t] = DDD_MFMA32(w[0], b0, acc[t]);
@@ -212,23 +231,19 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
-                                             bool prio_ramp = false) {
-  (void)prio_ramp;
+                                             const int (&rows)[2][kKW]) {
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  // The wave's two 32-row tiles advance together: a dependent 32x32x2 chain
-  // issues only every ~85 cycles (measured), two independent accumulators keep
-  // the 64-cycle matrix pipe full, and each weight register feeds both tiles.
+  // The wave's two 32-row tiles advance together (two independent accumulator
+  // chains) and each weight register feeds both tiles.
   const int trow0 = ln.wave * 64 + j;
   const int trow1 = trow0 + 32;
   const float4* rowp0[kKW];
   const float4* rowp1[kKW];
 #pragma unroll
   for (int tap = 0; tap < kKW; ++tap) {
-    rowp0[tap] = reinterpret_cast<const float4*>(
-        in + tile_src_row(ln, trow0, tap - 2, p.N) * kHS + 16 * half);
-    rowp1[tap] = reinterpret_cast<const float4*>(
-        in + tile_src_row(ln, trow1, tap - 2, p.N) * kHS + 16 * half);
+    rowp0[tap] = reinterpret_cast<const float4*>(in + rows[0][tap] * kHS + 16 * half);
+    rowp1[tap] = reinterpret_cast<const float4*>(in + rows[1][tap] * kHS + 16 * half);
   }
   f32x16 acc0, acc1;
 #pragma unroll
@@ -253,7 +268,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
     acc1 = DDD_MFMA32(w[4 * g + 3], cur1.w, acc1);
     cur0 = nxt0;
     cur1 = nxt1;
-    // keep "read group g+1 of both tiles, then the 8 MFMAs of group g"
+    // schedule: read group g+1 of both tiles, then the 8 MFMAs of group g
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
     __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
   }
@@ -282,43 +297,56 @@ __device__ __forceinline__ void load_final(const DevParams& p, int lane,
 __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ in,
                                             float* __restrict__ out,
-                                            const float (&wf)[kFinSteps]) {
+                                            const float (&wf)[kFinSteps],
+                                            const int (&rows)[4][kKW]) {
   const int j = ln.lane & 15;
   const int quarter = ln.lane >> 4;
+  // Ten operand groups (tap, half-of-the-8-channels); each group is one
+  // ds_read_b128 per tile feeding four MFMAs per tile.  The four tiles'
+  // accumulators are independent chains issued round-robin (a dependent
+  // 16x16x4 needs 40 cycles, the pipe takes one every 32), and the reads of
+  // group g + 1 are issued before the 16 MFMAs of group g.
+  const float4* rowp[4][kKW];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int tap = 0; tap < kKW; ++tap)
+      rowp[t][tap] = reinterpret_cast<const float4*>(in + rows[t][tap] * kHS + 8 * quarter);
   f32x4 acc[4];
+  float4 cur[4], nxt[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    cur[t] = rowp[t][0][0];
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // the reads of group 0
 #pragma unroll
-  for (int tap = 0; tap < kKW; ++tap) {
-    const float* w = wf + tap * 8;
-    float4 v0[4], v1[4];
+  for (int g = 0; g < 10; ++g) {
+    if (g + 1 < 10) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int trow = ln.wave * 64 + t * 16 + j;
-      const float4* q = reinterpret_cast<const float4*>(
-          in + tile_src_row(ln, trow, tap - 2, p.N) * kHS + 8 * quarter);
-      v0[t] = q[0];
-      v1[t] = q[1];
+      for (int t = 0; t < 4; ++t) nxt[t] = rowp[t][(g + 1) >> 1][(g + 1) & 1];
     }
+    const float* w = wf + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[t] = DDD_MFMA16(w[0], v0[t].x, acc[t]);
-      acc[t] = DDD_MFMA16(w[1], v0[t].y, acc[t]);
-      acc[t] = DDD_MFMA16(w[2], v0[t].z, acc[t]);
-      acc[t] = DDD_MFMA16(w[3], v0[t].w, acc[t]);
-    }
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[0], cur[t].x, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[t] = DDD_MFMA16(w[4], v1[t].x, acc[t]);
-      acc[t] = DDD_MFMA16(w[5], v1[t].y, acc[t]);
-      acc[t] = DDD_MFMA16(w[6], v1[t].z, acc[t]);
-      acc[t] = DDD_MFMA16(w[7], v1[t].w, acc[t]);
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[1], cur[t].y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[2], cur[t].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[3], cur[t].w, acc[t]);
+    if (g + 1 < 10) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (group g + 1)
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA (group g)
   }
   const float wb = wf[40];
 #pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
+#pragma unroll
   for (int t = 0; t < 4; ++t) {
-    acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
     const int trow = ln.wave * 64 + t * 16 + j;
     *reinterpret_cast<float4*>(out + trow * kHS + 4 * quarter) =
         make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
@@ -349,6 +377,17 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   DDD_STAMP(0);
   const Lane ln = make_lane<kRows>(p, batch, opaque((int)threadIdx.x));
   sm.u[ln.row] = u;
+  // conv-tap source rows of this wave's two 32-row tiles (input + hidden
+  // layers): index math placed here, in the shadow of the LDS round trip below
+  int hid_rows[2][kKW];
+  int fin_rows[4][kKW];     // same for the output layer's four 16-row tiles
+  if (!p.fixed) {
+    tap_rows(ln, ln.wave * 64 + (ln.lane & 31), p.N, hid_rows[0]);
+    tap_rows(ln, ln.wave * 64 + 32 + (ln.lane & 31), p.N, hid_rows[1]);
+#pragma unroll
+    for (int t2 = 0; t2 < 4; ++t2)
+      tap_rows(ln, ln.wave * 64 + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
+  }
   if (!p.fixed) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
   const int spg = kRows / p.N;
   if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.P) {
@@ -374,22 +413,19 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
       const float2 v = sm.pm[sl * p.P + m];
       acc = acc + (which ? v.y : v.x);
     }
-    sm.fk[ln.row] = acc;
+    sm.fk[sl * kTrigMax + 2 * kk + which] = acc;
   }
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
+  // Four-wave groups must read them now (other waves rewrite sm.u as soon as
+  // they enter the next evaluation); a one-wave group reads them in the
+  // epilogue instead and saves 8 registers across the conv tower.
   float pch[kGMax];
   const int gl = p.G >> 1;
+  if (kRows != 64) {
 #pragma unroll
-  for (int g = 0; g < kGMax; ++g)
-    pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
-
-  // this grid point's cos / sin of the spatial phases: issued now, used last
-  float trig[kTrigMax];
-  if (p.forced && fast_forcing) {
-    const float* __restrict__ tr = p.trig + (size_t)opaque(ln.pos) * p.n_k * 2;
-#pragma unroll
-    for (int i = 0; i < kTrigMax; ++i) trig[i] = (i < 2 * p.n_k) ? tr[i] : 0.0f;
+    for (int g = 0; g < kGMax; ++g)
+      pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
 
   float net[16];
@@ -398,7 +434,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   if (!p.fixed) {
     float wfin[kFinSteps];
     DDD_STAMP(1);
-    if (!(ablate & 16)) input_layer(p, ln, sm.un, sm.hA, res.w_in);
+    if (!(ablate & 16)) input_layer(p, ln, sm.un, sm.hA, res.w_in, hid_rows);
     {   // first taps of the output layer: in flight while the hidden layers run
       const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
 #pragma unroll
@@ -409,7 +445,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
     for (int l = 1; l < p.L - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
       __syncthreads();
-      if (!(ablate & 8)) hidden_layer(p, ln, in, out, res.hid, (ablate & 32) != 0);
+      hidden_layer(p, ln, in, out, res.hid, hid_rows);
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
@@ -420,7 +456,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
     }
     __syncthreads();
     if (ablate & 32) __builtin_amdgcn_s_setprio(3);
-    if (!(ablate & 4)) final_layer(p, ln, in, out, wfin);
+    final_layer(p, ln, in, out, wfin, fin_rows);
     if (ablate & 32) __builtin_amdgcn_s_setprio(0);
     DDD_STAMP(3);
     __syncthreads();
@@ -442,6 +478,20 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   // with the null-space row staged in LDS at tab[4 + c]: per channel one
   // uniform branch, two broadcast ds_read_b128 at compile-time offsets and 8
   // FMAs -- no dependent address chain.
+  // this grid point's cos / sin of the spatial phases: issued at the top of
+  // the epilogue, consumed by its last statement
+  float4 trig4[kTrigMax / 4];
+  if (p.forced && fast_forcing) {
+    const float4* __restrict__ tr =
+        reinterpret_cast<const float4*>(p.trig) + (size_t)opaque(ln.pos) * (kTrigMax / 4);
+#pragma unroll
+    for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = tr[i];
+  }
+  if (kRows == 64) {
+#pragma unroll
+    for (int g = 0; g < kGMax; ++g)
+      pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
+  }
   float cf[kMaxDerivs][kGMax];
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d)
@@ -516,12 +566,19 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   }
   if (p.forced && !(ablate & 1)) {
     if (fast_forcing) {
-      // phase 3: combine with this grid point's cos / sin table
-      const float* __restrict__ fk = sm.fk + ln.sl * p.n_k * 2;
+      // phase 3: combine with this grid point's cos / sin table (both zero
+      // padded to 12 entries: no branches)
+      const float4* __restrict__ fk4 =
+          reinterpret_cast<const float4*>(sm.fk + ln.sl * kTrigMax);
       float total = 0.0f;
 #pragma unroll
-      for (int i = 0; i < kTrigMax; ++i)
-        if (i < 2 * p.n_k) total = fmaf(fk[i], trig[i], total);
+      for (int i = 0; i < kTrigMax / 4; ++i) {
+        const float4 f = fk4[i];
+        total = fmaf(f.x, trig4[i].x, total);
+        total = fmaf(f.y, trig4[i].y, total);
+        total = fmaf(f.z, trig4[i].z, total);
+        total = fmaf(f.w, trig4[i].w, total);
+      }
       r = r + total;
     } else if (ln.active) {
       r = r + forcing_at(p, p.frc + (size_t)(ln.gidx / p.N) * p.P, ln.pos, t);
@@ -543,7 +600,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& 
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
   const bool fast = p.forced && spg * p.P <= Shared<kRows>::kPmMax && p.n_k <= 6 &&
-                    spg * p.n_k * 2 <= Shared<kRows>::kFkMax && p.P < 256;
+                    spg * kTrigMax <= Shared<kRows>::kFkMax && p.P < 256;
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
   if (!p.fixed) {
@@ -552,6 +609,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& 
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
+  for (int i = tid; i < Shared<kRows>::kFkMax; i += kRows) sm.fk[i] = 0.0f;
   if (fast && tid < spg * p.P) {
     const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
     const long sample = (long)blockIdx.x * spg + fsl;
