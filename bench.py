@@ -51,7 +51,7 @@ def parse_args():
   ap.add_argument('--non-conservative', action='store_true')
   ap.add_argument('--baseline-stencils', action='store_true',
                   help='fixed polynomial stencils instead of the conv net')
-  ap.add_argument('--kernel', default='auto', choices=['auto', 'mfma', 'mfma64', 'mfma256', 'generic'])
+  ap.add_argument('--kernel', default='auto', choices=['auto', 'mfma', 'mfma64', 'mfma64w32', 'mfma256', 'generic'])
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
   return ap.parse_args()

@@ -21,7 +21,8 @@ ACTIVATIONS = {'relu': 0, 'relu6': 1, 'tanh': 2, 'softplus': 3, 'elu': 4}
 MODEL_TARGETS = {'coefficients': 0, 'space_derivatives': 1,
                  'time_derivative': 2, 'flux': 3}
 SCHEMES = {'euler': 0, 'midpoint': 1, 'bs3': 2, 'rk23': 2, 'rk4': 3}
-KERNELS = {'auto': 0, 'generic': 1, 'mfma': 2, 'mfma64': 3, 'mfma256': 4}
+KERNELS = {'auto': 0, 'generic': 1, 'mfma': 2, 'mfma64': 3, 'mfma256': 4,
+           'mfma64w32': 5}
 LAUNCH_MODES = {'persistent': 0, 'per_substep': 1}
 
 

@@ -119,7 +119,8 @@ struct ddd_model {
   bool mfma_ok = false;
   std::string mfma_reason;
   int kernel = DDD_KERNEL_GENERIC;   // resolved family
-  int force_rows = 0;                // 0 = automatic; 64 / 256 for A/B runs
+  int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
+  int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
   float* d_weights = nullptr;
@@ -342,24 +343,52 @@ int check_batch(const ddd_model* m, int batch) {
   return DDD_OK;
 }
 
-// Rows per workgroup of the MFMA path: one free-running wavefront per
-// workgroup when whole samples fit 64 rows, else 256 rows with block barriers.
-int mfma_rows(const ddd_model* m) {
-  if (m->force_rows == 64 || m->force_rows == 256) return m->force_rows;
-  return (m->dp.N <= 64 && 64 % m->dp.N == 0) ? 64 : 256;
+// Geometry of the MFMA path.  rows: grid points per workgroup; wave_rows: per
+// wavefront.  One free-running 64-row wavefront per workgroup when whole
+// samples fit 64 rows (optionally split over two 32-row wavefronts), else 256
+// rows on four wavefronts with block barriers.
+struct MfmaGeometry { int rows, wave_rows; };
+
+int device_simds() {
+  static int simds = 0;
+  if (simds == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      simds = prop.multiProcessorCount * 4;
+    if (simds <= 0) simds = 1024;
+  }
+  return simds;
+}
+
+MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
+  const bool fits64 = m->dp.N <= 64 && 64 % m->dp.N == 0;
+  if (m->force_rows == 256 || !fits64) return {256, 64};
+  if (m->force_rows == 64) return {64, 64};
+  if (m->force_rows == 32) return {64, 32};
+  // Measured on MI355X (profiles/r1_ablation.txt): two 32-row wavefronts per
+  // SIMD are slower than one 64-row wavefront even when the batch leaves half
+  // the wave slots empty (B = 1024: 73.6 vs 82.1 TFLOP/s), so the split is
+  // never chosen automatically; it stays selectable for A/B runs.
+  (void)batch;
+  return {64, 64};
 }
 
 int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
   if (a.batch == 0) return DDD_OK;
+  m->last_batch = a.batch;
   if (m->kernel == DDD_KERNEL_MFMA) {
-    const int rows = mfma_rows(m);
-    const int spg = rows / m->dp.N;
+    const MfmaGeometry geo = mfma_geometry(m, a.batch);
+    const int spg = geo.rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
-    if (rows == 64)
-      hipLaunchKernelGGL(ddd::mfma::substep_kernel<64>, dim3(blocks), dim3(64), 0, stream,
-                         m->dp, a);
+    if (geo.rows == 64 && geo.wave_rows == 64)
+      hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64>), dim3(blocks), dim3(64), 0,
+                         stream, m->dp, a);
+    else if (geo.rows == 64)
+      hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 32>), dim3(blocks), dim3(128), 0,
+                         stream, m->dp, a);
     else
-      hipLaunchKernelGGL(ddd::mfma::substep_kernel<256>, dim3(blocks), dim3(256), 0,
+      hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64>), dim3(blocks), dim3(256), 0,
                          stream, m->dp, a);
   } else {
     int rc = check_generic_lds(m, 0);
@@ -374,36 +403,40 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   return DDD_OK;
 }
 
-template <int kRows, typename ST>
+template <int kRows, int kWR, typename ST>
 void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
   if (hoist)
-    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, ST, true>), dim3(blocks),
-                       dim3(kRows), 0, stream, m->dp, a);
+    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true>), dim3(blocks),
+                       dim3(kRows / kWR * 64), 0, stream, m->dp, a);
   else
-    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, ST, false>), dim3(blocks),
-                       dim3(kRows), 0, stream, m->dp, a);
+    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, false>), dim3(blocks),
+                       dim3(kRows / kWR * 64), 0, stream, m->dp, a);
 }
 
 template <typename ST>
 int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
+  m->last_batch = a.batch;
   {
-    const char* env = std::getenv("DDD_PRIO_SPLIT");   // A/B switch, default off
+    // profiling knobs (see profiles/r1_ablation.txt); all off by default
+    const char* env = std::getenv("DDD_PRIO_SPLIT");
     a.prio_split = env != nullptr ? std::atoi(env) : 0;
     const char* stg = std::getenv("DDD_STAGGER");
     a.stagger = stg != nullptr ? std::atoi(stg) : 0;
-    const char* trc = std::getenv("DDD_TRACE_PTR");   // profiling only: device buffer address
+    const char* trc = std::getenv("DDD_TRACE_PTR");   // device buffer address
     a.trace = trc != nullptr ? reinterpret_cast<unsigned long long*>(std::strtoull(trc, nullptr, 0))
                              : nullptr;
-    const char* abl = std::getenv("DDD_ABLATE");   // profiling only: WRONG RESULTS
+    const char* abl = std::getenv("DDD_ABLATE");      // skips phases: WRONG RESULTS
     a.ablate = abl != nullptr ? std::atoi(abl) : 0;
   }
   if (m->kernel == DDD_KERNEL_MFMA) {
-    if (mfma_rows(m) == 64) launch_mfma_integrate<64, ST>(m, a, stream);
-    else launch_mfma_integrate<256, ST>(m, a, stream);
+    const MfmaGeometry geo = mfma_geometry(m, a.batch);
+    if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
+    else if (geo.rows == 64) launch_mfma_integrate<64, 32, ST>(m, a, stream);
+    else launch_mfma_integrate<256, 64, ST>(m, a, stream);
   } else {
     int rc = check_generic_lds(m, (int)sizeof(ST));
     if (rc) return rc;
@@ -845,14 +878,17 @@ int ddd_set_kernel(ddd_model* m, int kind) {
     case DDD_KERNEL_MFMA:
     case DDD_KERNEL_MFMA_ROWS64:
     case DDD_KERNEL_MFMA_ROWS256:
+    case DDD_KERNEL_MFMA_ROWS64_W32:
       if (!m->mfma_ok)
         return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
                     m->mfma_reason.c_str());
-      if (kind == DDD_KERNEL_MFMA_ROWS64 && !(m->dp.N <= 64 && 64 % m->dp.N == 0))
+      if ((kind == DDD_KERNEL_MFMA_ROWS64 || kind == DDD_KERNEL_MFMA_ROWS64_W32) &&
+          !(m->dp.N <= 64 && 64 % m->dp.N == 0))
         return fail(DDD_ERR_UNSUPPORTED,
                     "64-row workgroups need num_points to divide 64 (got %d)", m->dp.N);
       m->kernel = DDD_KERNEL_MFMA;
       m->force_rows = kind == DDD_KERNEL_MFMA_ROWS64 ? 64
+                      : kind == DDD_KERNEL_MFMA_ROWS64_W32 ? 32
                       : kind == DDD_KERNEL_MFMA_ROWS256 ? 256 : 0;
       return DDD_OK;
     default:
@@ -863,7 +899,9 @@ int ddd_set_kernel(ddd_model* m, int kind) {
 const char* ddd_kernel_name(const ddd_model* m) {
   if (m == nullptr) return "";
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
-  return mfma_rows(m) == 64 ? "mfma_f32_r64" : "mfma_f32_r256";
+  const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
+  if (geo.rows == 256) return "mfma_f32_r256";
+  return geo.wave_rows == 32 ? "mfma_f32_r64w32" : "mfma_f32_r64";
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }

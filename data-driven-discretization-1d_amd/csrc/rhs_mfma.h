@@ -2,9 +2,11 @@
 //
 // Work decomposition (DESIGN.md "MFMA kernel"):
 //   * one workgroup = kRows "rows" (grid points) = floor(kRows / N) whole
-//     samples; wavefront w owns rows [64 w, 64 w + 64).  kRows = 64 (one
-//     free-running wavefront per workgroup) when samples fit a wavefront
-//     (64 % N == 0), else 256 (four wavefronts, block barriers between layers);
+//     samples; wavefront w owns rows [kWR w, kWR w + kWR), kWR = 64 or 32.
+//     <64, 64>: one free-running wavefront per workgroup when samples fit a
+//     wavefront (64 % N == 0); <64, 32>: the same 64 rows on two wavefronts,
+//     for batches too small to give every SIMD two 64-row wavefronts;
+//     <256, 64>: four wavefronts with block barriers between layers (any N <= 256);
 //   * the conv tower runs on the matrix cores as implicit GEMMs
 //         D[out-channel][position] += W[out-channel][k] * h[k][position],
 //     reduction index k = (tap, in-channel):
@@ -48,7 +50,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // no cross-wave dependency, wavefronts free-run and eight workgroups share a
 // CU).  Sizes are chosen so that 160 KiB of LDS hold 2 x 256-row or 8 x 64-row
 // workgroups.
-template <int kRows>
+template <int kRows, int kWR = 64>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
   static constexpr int kFkMax = 3 * kRows / 4;  // samples * 12 harmonic sums (zero padded)
@@ -56,7 +58,7 @@ struct Shared {
   float hB[kRows * kHS];
   float u[kRows];
   float un[kRows];                // u / standard_deviation (input-layer operand)
-  float flux[kRows == 64 ? 1 : kRows];   // 64-row groups exchange flux by shuffle
+  float flux[kRows == kWR ? 1 : kRows];  // one-wave groups exchange flux by shuffle
   float2 pm[kPmMax];              // per (sample, mode): a sin(psi), a cos(psi)
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
   unsigned char ks[kRows];        // per sample: start of each k's run of modes, [8]
@@ -64,6 +66,7 @@ struct Shared {
 };
 static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
 static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
+static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
 
 // Value the optimiser must treat as unknown: stops loop-invariant code motion
 // from hoisting per-evaluation index math and loads out of the time loop (where
@@ -78,9 +81,11 @@ struct Lane {
   int base;      // first row of the row's sample
   int pos;       // grid index inside the sample
   int sl;        // sample index inside the workgroup
-  int active;    // row maps to a real sample of the batch
+  int valid;     // row maps to a real sample of the batch
+  int active;    // valid and this lane owns the row's stores
   long gidx;     // sample * N + pos (global element index), valid if active
   int wave, lane;
+  int owner;     // this lane stores the row's results (kWR = 32: lanes 0..31 only)
   int rows_used; // samples_per_group * N
   float inv_n;
 };
@@ -91,12 +96,15 @@ __device__ __forceinline__ int row_sample(int row, float inv_n) {
   return (int)(((float)row + 0.5f) * inv_n);
 }
 
-template <int kRows>
+template <int kRows, int kWR>
 __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid) {
   Lane ln;
-  ln.row = tid;
   ln.wave = tid >> 6;
   ln.lane = tid & 63;
+  // kWR = 32: both half-waves carry the same 32 rows through the VALU phases
+  // (identical values), the lower half owns the stores
+  ln.row = ln.wave * kWR + (ln.lane & (kWR - 1));
+  ln.owner = ln.lane < kWR;
   const int spg = kRows / p.N;
   ln.rows_used = spg * p.N;
   ln.inv_n = 1.0f / (float)p.N;
@@ -109,7 +117,8 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid
     ln.sl = 0; ln.base = 0; ln.pos = 0;
   }
   const long sample = (long)blockIdx.x * spg + ln.sl;
-  ln.active = (ln.row < ln.rows_used) && (sample < batch);
+  ln.valid = (ln.row < ln.rows_used) && (sample < batch);
+  ln.active = ln.valid && ln.owner;
   ln.gidx = sample * p.N + ln.pos;
   return ln;
 }
@@ -195,16 +204,18 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 // Input layer 1 -> 32 for this wave's two 32-row tiles (3 MFMA steps each).
 //   A: lane l supplies W1[out = l & 31][k = 2 s + (l >> 5)]  (k = tap; k = 5: bias)
 //   B: lane l supplies un[(pos(l & 31) + k - 2) mod N], un = u / std   (k = 5: 1.0)
+template <int kWR>
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ us,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps],
                                             const int (&rows)[2][kKW]) {
+  constexpr int kT = kWR / 32;
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  f32x16 acc[2];
+  f32x16 acc[kT];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < kT; ++t) {
     const float b0 = us[half ? rows[t][1] : rows[t][0]];        // taps 0 / 1
     const float b1 = us[half ? rows[t][3] : rows[t][2]];        // taps 2 / 3
     const float b2 = half ? 1.0f : us[rows[t][4]];              // tap 4 / bias row
@@ -215,72 +226,75 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
     acc[t] = DDD_MFMA32(w[2], b2, acc[t]);
   }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < kT; ++t) {
     activate16(acc[t], p.act);
-    store_tile32(out, ln.wave * 64 + t * 32 + j, half, acc[t]);
+    store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
 
-// One hidden layer for this wave's two 32-row tiles.
+// One hidden layer for this wave's 32-row tiles (two, or one when kWR = 32).
 //   A operand (weights): lane l supplies W[out = l & 31][k = 2 s + (l >> 5)]
 //   B operand (acts)   : lane l supplies h[k = 2 s + (l >> 5)][position = l & 31]
 //   reduction index    : step s = 16 tap + jj, half = l >> 5  <->  (tap, cin = 16 half + jj)
 // The 16 floats a lane needs per tap are four ds_read_b128; the read of group
 // g + 1 is issued before the four MFMAs of group g (software prefetch).
+template <int kWR>
 __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
                                              const int (&rows)[2][kKW]) {
+  constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  // The wave's two 32-row tiles advance together (two independent accumulator
-  // chains) and each weight register feeds both tiles.
-  const int trow0 = ln.wave * 64 + j;
-  const int trow1 = trow0 + 32;
-  const float4* rowp0[kKW];
-  const float4* rowp1[kKW];
+  const float4* rowp[kT][kKW];
 #pragma unroll
-  for (int tap = 0; tap < kKW; ++tap) {
-    rowp0[tap] = reinterpret_cast<const float4*>(in + rows[0][tap] * kHS + 16 * half);
-    rowp1[tap] = reinterpret_cast<const float4*>(in + rows[1][tap] * kHS + 16 * half);
+  for (int t = 0; t < kT; ++t)
+#pragma unroll
+    for (int tap = 0; tap < kKW; ++tap)
+      rowp[t][tap] = reinterpret_cast<const float4*>(in + rows[t][tap] * kHS + 16 * half);
+  f32x16 acc[kT];
+  float4 cur[kT], nxt[kT];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    cur[t] = rowp[t][0][0];
   }
-  f32x16 acc0, acc1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-  float4 cur0 = rowp0[0][0];
-  float4 cur1 = rowp1[0][0];
-  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // the reads of group 0
+  __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
 #pragma unroll
   for (int g = 0; g < 20; ++g) {
-    float4 nxt0 = cur0, nxt1 = cur1;
-    if (g + 1 < 20) {
-      nxt0 = rowp0[(g + 1) >> 2][(g + 1) & 3];
-      nxt1 = rowp1[(g + 1) >> 2][(g + 1) & 3];
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      nxt[t] = cur[t];
+      if (g + 1 < 20) nxt[t] = rowp[t][(g + 1) >> 2][(g + 1) & 3];
     }
-    acc0 = DDD_MFMA32(w[4 * g + 0], cur0.x, acc0);
-    acc1 = DDD_MFMA32(w[4 * g + 0], cur1.x, acc1);
-    acc0 = DDD_MFMA32(w[4 * g + 1], cur0.y, acc0);
-    acc1 = DDD_MFMA32(w[4 * g + 1], cur1.y, acc1);
-    acc0 = DDD_MFMA32(w[4 * g + 2], cur0.z, acc0);
-    acc1 = DDD_MFMA32(w[4 * g + 2], cur1.z, acc1);
-    acc0 = DDD_MFMA32(w[4 * g + 3], cur0.w, acc0);
-    acc1 = DDD_MFMA32(w[4 * g + 3], cur1.w, acc1);
-    cur0 = nxt0;
-    cur1 = nxt1;
-    // schedule: read group g+1 of both tiles, then the 8 MFMAs of group g
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // 2 DS reads
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // 8 MFMA
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[4 * g + 0], cur[t].x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[4 * g + 1], cur[t].y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[4 * g + 2], cur[t].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[4 * g + 3], cur[t].w, acc[t]);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) cur[t] = nxt[t];
+    // schedule: read group g+1 of every tile, then the MFMAs of group g
+    __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);       // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kT, 0);   // MFMAs
   }
-  acc0 = DDD_MFMA32(w[80], 1.0f, acc0);   // bias row: k = 160 carries b[out]
-  acc1 = DDD_MFMA32(w[80], 1.0f, acc1);
-  activate16(acc0, p.act);
-  activate16(acc1, p.act);
-  store_tile32(out, trow0, half, acc0);
-  store_tile32(out, trow1, half, acc1);
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+    acc[t] = DDD_MFMA32(w[80], 1.0f, acc[t]);   // bias row: k = 160 carries b[out]
+  }
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+    activate16(acc[t], p.act);
+    store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
+  }
 }
 
-// Output layer (32 -> C_out <= 16, linear) for this wave's four 16-row tiles.
+// Output layer (32 -> C_out <= 16, linear) for this wave's 16-row tiles (4 or 2).
 //   A: lane l supplies W[out = l & 15][k = 4 s + (l >> 4)]
 //   B: lane l supplies h[k = 4 s + (l >> 4)][position = l & 15]
 //   step s = 8 tap + jj, quarter = l >> 4  <->  (tap, cin = 8 quarter + jj)
@@ -294,60 +308,62 @@ __device__ __forceinline__ void load_final(const DevParams& p, int lane,
   for (int s = 0; s < kFinSteps; ++s) w[s] = src[s * 64];
 }
 
+template <int kWR>
 __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ in,
                                             float* __restrict__ out,
                                             const float (&wf)[kFinSteps],
                                             const int (&rows)[4][kKW]) {
+  constexpr int kT = kWR / 16;   // 16-row tiles of this wave
   const int j = ln.lane & 15;
   const int quarter = ln.lane >> 4;
   // Ten operand groups (tap, half-of-the-8-channels); each group is one
-  // ds_read_b128 per tile feeding four MFMAs per tile.  The four tiles'
+  // ds_read_b128 per tile feeding four MFMAs per tile.  The tiles'
   // accumulators are independent chains issued round-robin (a dependent
   // 16x16x4 needs 40 cycles, the pipe takes one every 32), and the reads of
-  // group g + 1 are issued before the 16 MFMAs of group g.
-  const float4* rowp[4][kKW];
+  // group g + 1 are issued before the MFMAs of group g.
+  const float4* rowp[kT][kKW];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
       rowp[t][tap] = reinterpret_cast<const float4*>(in + rows[t][tap] * kHS + 8 * quarter);
-  f32x4 acc[4];
-  float4 cur[4], nxt[4];
+  f32x4 acc[kT];
+  float4 cur[kT], nxt[kT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
+  for (int t = 0; t < kT; ++t) {
     acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     cur[t] = rowp[t][0][0];
   }
-  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // the reads of group 0
+  __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
 #pragma unroll
   for (int g = 0; g < 10; ++g) {
     if (g + 1 < 10) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) nxt[t] = rowp[t][(g + 1) >> 1][(g + 1) & 1];
+      for (int t = 0; t < kT; ++t) nxt[t] = rowp[t][(g + 1) >> 1][(g + 1) & 1];
     }
     const float* w = wf + 4 * g;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[0], cur[t].x, acc[t]);
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[0], cur[t].x, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[1], cur[t].y, acc[t]);
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[1], cur[t].y, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[2], cur[t].z, acc[t]);
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[2], cur[t].z, acc[t]);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[3], cur[t].w, acc[t]);
+    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[3], cur[t].w, acc[t]);
     if (g + 1 < 10) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+      for (int t = 0; t < kT; ++t) cur[t] = nxt[t];
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // 4 DS reads (group g + 1)
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);  // 16 MFMA (group g)
+    __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);       // DS reads (group g + 1)
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kT, 0);   // MFMAs (group g)
   }
   const float wb = wf[40];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
+  for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int trow = ln.wave * 64 + t * 16 + j;
+  for (int t = 0; t < kT; ++t) {
+    const int trow = ln.wave * kWR + t * 16 + j;
     *reinterpret_cast<float4*>(out + trow * kHS + 4 * quarter) =
         make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
   }
@@ -367,30 +383,33 @@ struct Resident {
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
-template <int kRows, bool kHoist>
-__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm, int batch,
+template <int kRows, int kWR, bool kHoist>
+__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
                                           float u, float t, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
                                           unsigned long long* trace = nullptr) {
 #define DDD_STAMP(i) do { if (trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
-  const Lane ln = make_lane<kRows>(p, batch, opaque((int)threadIdx.x));
-  sm.u[ln.row] = u;
+  constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
+  const int tid = opaque((int)threadIdx.x);
+  const Lane ln = make_lane<kRows, kWR>(p, batch, tid);
+  if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][kKW];
   int fin_rows[4][kKW];     // same for the output layer's four 16-row tiles
   if (!p.fixed) {
-    tap_rows(ln, ln.wave * 64 + (ln.lane & 31), p.N, hid_rows[0]);
-    tap_rows(ln, ln.wave * 64 + 32 + (ln.lane & 31), p.N, hid_rows[1]);
 #pragma unroll
-    for (int t2 = 0; t2 < 4; ++t2)
-      tap_rows(ln, ln.wave * 64 + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
+    for (int t2 = 0; t2 < kWR / 32; ++t2)
+      tap_rows(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
+#pragma unroll
+    for (int t2 = 0; t2 < kWR / 16; ++t2)
+      tap_rows(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
   }
-  if (!p.fixed) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
+  if (!p.fixed && ln.owner) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
   const int spg = kRows / p.N;
-  if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.P) {
+  if (p.forced && fast_forcing && !(ablate & 1) && tid < spg * p.P) {
     // forcing, phase 1: one (sample, mode) pair per lane.
     //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
     //     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
@@ -398,15 +417,15 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
     float sn, cs;
     sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
     const float2 v = make_float2(res.frc_a * sn, res.frc_a * cs);
-    sm.pm[ln.row] = v;
+    sm.pm[tid] = v;
   }
   __syncthreads();
-  if (p.forced && fast_forcing && !(ablate & 1) && ln.row < spg * p.n_k * 2) {
+  if (p.forced && fast_forcing && !(ablate & 1) && tid < spg * p.n_k * 2) {
     // phase 2: per (sample, k, sin|cos) sum over the modes carrying that k.
     // Modes are stored sorted by k (ddd_set_forcing), so the run is contiguous.
-    const int which = ln.row & 1;
-    const int sl = row_sample(ln.row >> 1, 1.0f / (float)p.n_k);   // exact
-    const int kk = (ln.row >> 1) - sl * p.n_k;
+    const int which = tid & 1;
+    const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
+    const int kk = (tid >> 1) - sl * p.n_k;
     const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
     float acc = 0.0f;
     for (int m = m0; m < m1; ++m) {
@@ -422,7 +441,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   // epilogue instead and saves 8 registers across the conv tower.
   float pch[kGMax];
   const int gl = p.G >> 1;
-  if (kRows != 64) {
+  if (!kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
       pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
@@ -434,7 +453,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   if (!p.fixed) {
     float wfin[kFinSteps];
     DDD_STAMP(1);
-    if (!(ablate & 16)) input_layer(p, ln, sm.un, sm.hA, res.w_in, hid_rows);
+    if (!(ablate & 16)) input_layer<kWR>(p, ln, sm.un, sm.hA, res.w_in, hid_rows);
     {   // first taps of the output layer: in flight while the hidden layers run
       const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
 #pragma unroll
@@ -445,7 +464,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
     for (int l = 1; l < p.L - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
       __syncthreads();
-      hidden_layer(p, ln, in, out, res.hid, hid_rows);
+      hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows);
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
@@ -455,9 +474,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
       for (int s2 = kFinPrefetch; s2 < kFinSteps; ++s2) wfin[s2] = wsrc[s2 * 64];
     }
     __syncthreads();
-    if (ablate & 32) __builtin_amdgcn_s_setprio(3);
-    final_layer(p, ln, in, out, wfin, fin_rows);
-    if (ablate & 32) __builtin_amdgcn_s_setprio(0);
+    final_layer<kWR>(p, ln, in, out, wfin, fin_rows);
     DDD_STAMP(3);
     __syncthreads();
     const float4* nrow = reinterpret_cast<const float4*>(out + ln.row * kHS);
@@ -487,7 +504,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
 #pragma unroll
     for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = tr[i];
   }
-  if (kRows == 64) {
+  if (kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
       pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
@@ -553,12 +570,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
   float r = equation_rhs_or_flux(p.equation, u, dv, p.eta);
   if (p.conservative) {
     float fnext;
-    if (kRows == 64) {
+    if (kOneWave) {
       // whole samples live in this wavefront: the right neighbour's flux comes
       // straight from its lane
       fnext = __shfl(r, wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
-      sm.flux[ln.row] = r;
+      if (ln.owner) sm.flux[ln.row] = r;
       __syncthreads();
       fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     }
@@ -580,7 +597,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
         total = fmaf(f.w, trig4[i].w, total);
       }
       r = r + total;
-    } else if (ln.active) {
+    } else if (ln.valid) {
       r = r + forcing_at(p, p.frc + (size_t)(ln.gidx / p.N) * p.P, ln.pos, t);
     }
   }
@@ -590,17 +607,18 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows>& sm,
 }
 
 // Per-launch setup: resident registers and the per-sample tables in LDS.
-template <int kRows, bool kHoist>
-__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& sm,
+template <int kRows, int kWR, bool kHoist>
+__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
                                              const Lane& ln, int batch, Resident& res) {
+  constexpr int kThreads = kRows / kWR * 64;
   const int tid = threadIdx.x;
   const int spg = kRows / p.N;
-  for (int i = tid; i < kTabRows * kGMax; i += kRows) {
+  for (int i = tid; i < kTabRows * kGMax; i += kThreads) {
     const int rowi = i / kGMax, g = i % kGMax;
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
-  const bool fast = p.forced && spg * p.P <= Shared<kRows>::kPmMax && p.n_k <= 6 &&
-                    spg * kTrigMax <= Shared<kRows>::kFkMax && p.P < 256;
+  const bool fast = p.forced && spg * p.P <= Shared<kRows, kWR>::kPmMax && p.n_k <= 6 &&
+                    spg * kTrigMax <= Shared<kRows, kWR>::kFkMax && p.P < 256;
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
   if (!p.fixed) {
@@ -609,7 +627,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& 
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
-  for (int i = tid; i < Shared<kRows>::kFkMax; i += kRows) sm.fk[i] = 0.0f;
+  for (int i = tid; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
   if (fast && tid < spg * p.P) {
     const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
     const long sample = (long)blockIdx.x * spg + fsl;
@@ -637,15 +655,16 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows>& 
 // Kernel 1: one fused RK substep (also: plain time derivative, derivative and
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
-template <int kRows>
-__global__ __launch_bounds__(kRows, 2) void substep_kernel(DevParams p, SubstepArgs a) {
-  __shared__ Shared<kRows> sm;
-  const Lane ln = make_lane<kRows>(p, a.batch, threadIdx.x);
+template <int kRows, int kWR>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams p,
+                                                                      SubstepArgs a) {
+  __shared__ Shared<kRows, kWR> sm;
+  const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, false>(p, sm, ln, a.batch, res);
-  const float u = ln.active ? a.y_in[ln.gidx] : 0.0f;
-  const float f = eval_rhs<kRows, false>(p, sm, a.batch, u, (float)a.t, res, fast_frc,
-                                         a.derivs_out, a.coeffs_out);
+  const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
+  const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
+  const float f = eval_rhs<kRows, kWR, false>(p, sm, a.batch, u, (float)a.t, res,
+                                              fast_frc, a.derivs_out, a.coeffs_out);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
     const float cf = a.c1 * f;
@@ -662,12 +681,13 @@ __global__ __launch_bounds__(kRows, 2) void substep_kernel(DevParams p, SubstepA
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-template <int kRows, typename ST, bool kHoist>
-__global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, IntegrateArgs a) {
-  __shared__ Shared<kRows> sm;
-  const Lane ln = make_lane<kRows>(p, a.batch, threadIdx.x);
+template <int kRows, int kWR, typename ST, bool kHoist>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
+                                                                        IntegrateArgs a) {
+  __shared__ Shared<kRows, kWR> sm;
+  const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kHoist>(p, sm, ln, a.batch, res);
+  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
   // Two wavefronts share each SIMD and run the same phases; left alone they
   // phase-lock (both in their MFMA phase, then both in their VALU phase, the
   // matrix pipe idling).  A static priority split by hardware wave slot lets
@@ -688,7 +708,7 @@ __global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, Integr
   }
   const ST* y0 = static_cast<const ST*>(a.y0);
   ST* y_out = static_cast<ST*>(a.y_out);
-  ST y = ln.active ? y0[ln.gidx] : (ST)0;
+  ST y = ln.valid ? y0[ln.gidx] : (ST)0;   // both half-waves carry the state
   const ST h = (ST)a.dt;
   const size_t snap_stride = (size_t)a.batch * p.N;
   int until_save = a.save_every;
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(kRows, 2) void integrate_kernel(DevParams p, Integr
       if (a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
         tr = a.trace + (size_t)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
-      const float f = eval_rhs<kRows, kHoist>(p, sm, a.batch, (float)us,
+      const float f = eval_rhs<kRows, kWR, kHoist>(p, sm, a.batch, (float)us,
                                               (float)(t + a.tab.c[s] * a.dt), res,
                                               fast_frc, nullptr, nullptr, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;

@@ -100,7 +100,8 @@ typedef enum ddd_kernel_kind {
   DDD_KERNEL_GENERIC = 1, /* any configuration, scalar FMA, one block / sample */
   DDD_KERNEL_MFMA = 2,    /* f32 MFMA tiles; 64 or 256 grid points / block    */
   DDD_KERNEL_MFMA_ROWS64 = 3,  /* force one-wavefront workgroups (N divides 64) */
-  DDD_KERNEL_MFMA_ROWS256 = 4  /* force four-wavefront workgroups               */
+  DDD_KERNEL_MFMA_ROWS256 = 4, /* force four-wavefront workgroups               */
+  DDD_KERNEL_MFMA_ROWS64_W32 = 5 /* force 64-row groups on two 32-row wavefronts */
 } ddd_kernel_kind;
 
 /* How ddd_integrate_fixed advances time. */
@@ -259,8 +260,9 @@ int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
 
 /* ---- introspection -------------------------------------------------------*/
 int ddd_set_kernel(ddd_model* model, int kernel_kind);
-/* "mfma_f32_r64", "mfma_f32_r256" or "generic": the kernel family (and rows per
- * workgroup) launches on this handle use. */
+/* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256" or "generic": the kernel
+ * family and workgroup geometry of the most recent launch on this handle (the
+ * automatic choice depends on the batch size). */
 const char* ddd_kernel_name(const ddd_model* model);
 /* Algorithmic multiply-adds per grid point per right-hand-side evaluation
  * (SURVEY.md section 8(d)); 2x this is the FLOP count used for the roofline. */

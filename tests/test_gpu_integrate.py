@@ -14,7 +14,7 @@ SCHEMES = {'euler': oracle.SCHEME_EULER, 'midpoint': oracle.SCHEME_MIDPOINT,
 
 
 @pytest.mark.parametrize('scheme', ['euler', 'midpoint', 'bs3', 'rk4'])
-@pytest.mark.parametrize('kernel', ['mfma64', 'mfma256', 'generic'])
+@pytest.mark.parametrize('kernel', ['mfma64', 'mfma64w32', 'mfma256', 'generic'])
 def test_fixed_step_schemes_vs_oracle(scheme, kernel):
   model = make_model('burgers', True, num_points=64, resample_factor=8)
   model.set_kernel(kernel)

@@ -51,7 +51,7 @@ def _check_all_views(model, y0, t, forcing, tol):
   return err
 
 
-@pytest.mark.parametrize('kernel', ['mfma64', 'mfma256', 'generic'])
+@pytest.mark.parametrize('kernel', ['mfma64', 'mfma64w32', 'mfma256', 'generic'])
 @pytest.mark.parametrize('equation,conservative,numerical_flux', ALL_EQUATIONS)
 def test_time_derivative_all_equations(equation, conservative, numerical_flux,
                                        kernel):
@@ -242,12 +242,17 @@ def test_conservation_large_batch():
 
 
 def test_rows_per_workgroup_selection():
-  """One free-running wavefront per workgroup when N divides 64, else 256 rows."""
-  for n, name in [(64, 'mfma_f32_r64'), (32, 'mfma_f32_r64'), (16, 'mfma_f32_r64'),
-                  (48, 'mfma_f32_r256'), (128, 'mfma_f32_r256'),
-                  (256, 'mfma_f32_r256')]:
+  """Geometry: one free-running 64-row wavefront per workgroup when N divides
+  64 (two 32-row wavefronts on request), else 256 rows."""
+  for n, name in [(64, 'mfma_f32_r64'), (32, 'mfma_f32_r64'),
+                  (16, 'mfma_f32_r64'), (48, 'mfma_f32_r256'),
+                  (128, 'mfma_f32_r256'), (256, 'mfma_f32_r256')]:
     model = make_model('kdv', False, num_points=n, resample_factor=1)
+    model.time_derivative(random_phase_ic(model.equation, 3), 0.0)   # small batch
     assert model.kernel_name == name, (n, model.kernel_name)
+  model = make_model('kdv', False, num_points=64, resample_factor=1)
+  model.set_kernel('mfma64w32')
+  assert model.kernel_name == 'mfma_f32_r64w32'
   model = make_model('kdv', False, num_points=48, resample_factor=1)
   with pytest.raises(Exception, match='divide 64'):
     model.set_kernel('mfma64')
@@ -255,8 +260,11 @@ def test_rows_per_workgroup_selection():
   y0 = random_phase_ic(model.equation, 11)
   forcing = batch_forcing(11)
   model.set_forcing(forcing)
-  a = model.time_derivative(y0, 0.4).cpu().numpy()
-  model.set_kernel('mfma256')
+  results = {}
+  for kind in ('mfma64', 'mfma64w32', 'mfma256'):
+    model.set_kernel(kind)
+    results[kind] = model.time_derivative(y0, 0.4).cpu().numpy()
   assert model.kernel_name == 'mfma_f32_r256'
-  b = model.time_derivative(y0, 0.4).cpu().numpy()
-  np.testing.assert_array_equal(a, b)    # same arithmetic, different tiling
+  # same arithmetic, different tiling
+  np.testing.assert_array_equal(results['mfma64'], results['mfma64w32'])
+  np.testing.assert_array_equal(results['mfma64'], results['mfma256'])
