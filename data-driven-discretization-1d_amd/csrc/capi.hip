@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/ddd1d.h"
@@ -403,11 +404,46 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   return DDD_OK;
 }
 
+// Equation id of the compile-time specialised integrator this model can use,
+// or -1: the default architecture (three relu conv layers, default stencil
+// width, projection folded when D <= 2) on a non-Godunov equation.
+int spec_equation(const ddd_model* m) {
+  const ddd::DevParams& dp = m->dp;
+  const char* off = std::getenv("DDD_NO_SPEC");
+  if (off != nullptr && off[0] == '1') return -1;
+  if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
+  if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
+  if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
+  if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
+  if ((dp.conservative != 0) != ddd::mfma::spec_flux_form(dp.equation)) return -1;
+  if ((dp.folded != 0) != (dp.D <= 2)) return -1;
+  return dp.equation;
+}
+
 template <int kRows, int kWR, typename ST>
 void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
+  if constexpr (kWR == 64 && std::is_same<ST, float>::value) {
+    // float32 state on 64-row wavefronts: per-equation instantiations
+    const dim3 grid(blocks), block(kRows / kWR * 64);
+#define DDD_SPEC_CASE(EQ)                                                              \
+    case EQ:                                                                           \
+      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true, EQ>), grid, \
+                         block, 0, stream, m->dp, a);                                  \
+      return;
+    switch (spec_equation(m)) {
+      DDD_SPEC_CASE(ddd::EQ_BURGERS)
+      DDD_SPEC_CASE(ddd::EQ_BURGERS_CONS)
+      DDD_SPEC_CASE(ddd::EQ_KDV)
+      DDD_SPEC_CASE(ddd::EQ_KDV_CONS)
+      DDD_SPEC_CASE(ddd::EQ_KS)
+      DDD_SPEC_CASE(ddd::EQ_KS_CONS)
+      default: break;
+    }
+#undef DDD_SPEC_CASE
+  }
   if (hoist)
     hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true>), dim3(blocks),
                        dim3(kRows / kWR * 64), 0, stream, m->dp, a);

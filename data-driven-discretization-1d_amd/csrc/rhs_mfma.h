@@ -76,6 +76,20 @@ __device__ __forceinline__ int opaque(int x) {
   return x;
 }
 
+// Compile-time specialisation of the evaluation on the equation (kEq >= 0):
+// derivative count, stencil width and flux form become constants, the net is
+// the default relu tower with the projection folded into the output layer
+// where D <= 2.  kEq = -1 keeps every parameter a run-time (wave-uniform)
+// value.  The host picks a specialised instantiation only when the model
+// matches these assumptions (capi.hip: spec_equation).
+__host__ __device__ constexpr int spec_derivs(int eq) {
+  return (eq == EQ_KS || eq == EQ_KS_CONS) ? 3 : 2;
+}
+__host__ __device__ constexpr bool spec_flux_form(int eq) {
+  return eq == EQ_BURGERS_CONS || eq == EQ_KDV_CONS || eq == EQ_KS_CONS;
+}
+__host__ __device__ constexpr int spec_stencil(int eq) { return spec_flux_form(eq) ? 6 : 7; }
+
 struct Lane {
   int row;       // row inside the workgroup this lane owns in VALU phases
   int base;      // first row of the row's sample
@@ -108,9 +122,15 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid
   const int spg = kRows / p.N;
   ln.rows_used = spg * p.N;
   ln.inv_n = 1.0f / (float)p.N;
-  ln.sl = row_sample(ln.row, ln.inv_n);
-  ln.base = ln.sl * p.N;
-  ln.pos = ln.row - ln.base;
+  if ((p.N & (p.N - 1)) == 0) {   // wave-uniform
+    ln.pos = ln.row & (p.N - 1);
+    ln.base = ln.row - ln.pos;
+    ln.sl = ln.row >> (31 - __builtin_clz(p.N));
+  } else {
+    ln.sl = row_sample(ln.row, ln.inv_n);
+    ln.base = ln.sl * p.N;
+    ln.pos = ln.row - ln.base;
+  }
   if (ln.row >= ln.rows_used) {
     // Spare rows (256 is not a multiple of N): read like row 0 of sample 0 so
     // every LDS index stays in range; results are never stored.
@@ -144,6 +164,19 @@ __device__ __forceinline__ int tile_src_row(const Lane& ln, int trow, int off, i
 // (the sign of each offset is known at compile time).
 __device__ __forceinline__ void tap_rows(const Lane& ln, int trow, int n,
                                          int (&rows)[kKW]) {
+  if ((n & (n - 1)) == 0) {
+    // N a power of two (divides the group's rows, no spare rows): samples
+    // start at multiples of N, so the wrap is an AND and the base an OR:
+    // one v_add + one v_and_or per tap.  (wave-uniform branch)
+    const int mask = n - 1;
+    const int base = trow & ~mask;
+    rows[0] = ((trow - 2) & mask) | base;
+    rows[1] = ((trow - 1) & mask) | base;
+    rows[2] = trow;
+    rows[3] = ((trow + 1) & mask) | base;
+    rows[4] = ((trow + 2) & mask) | base;
+    return;
+  }
   const int base = row_sample(trow, ln.inv_n) * n;
   const int pos = trow - base;
   int qm2 = pos - 2; qm2 = qm2 < 0 ? qm2 + n : qm2;
@@ -209,7 +242,7 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ us,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps],
-                                            const int (&rows)[2][kKW]) {
+                                            const int (&rows)[2][kKW], int act) {
   constexpr int kT = kWR / 32;
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -227,7 +260,7 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
   }
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
-    activate16(acc[t], p.act);
+    activate16(acc[t], act);
     store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
@@ -243,7 +276,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
-                                             const int (&rows)[2][kKW]) {
+                                             const int (&rows)[2][kKW], int act) {
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -289,7 +322,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   }
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
-    activate16(acc[t], p.act);
+    activate16(acc[t], act);
     store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
@@ -374,7 +407,60 @@ struct Resident {
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
+  float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
 };
+
+// Index in Shared::fk of the harmonic sum lane `tid` carries: (sample, k,
+// sin|cos) = (tid / (2 n_k), (tid / 2) % n_k, tid & 1); -1 for other lanes.
+__device__ __forceinline__ int fk_slot_of(const DevParams& p, int tid, int spg) {
+  if (tid >= spg * p.n_k * 2) return -1;
+  const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
+  const int kk = (tid >> 1) - sl * p.n_k;
+  return sl * kTrigMax + 2 * kk + (tid & 1);
+}
+
+// Forcing, phases 1 + 2, for time t:
+//   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
+//     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
+//   psi_j = omega_j t + phi_j,  theta_j(x) = 2 pi k_j x / L  (<= 6 distinct k).
+// Phase 1: one (sample, mode) pair per lane -> Shared::pm.  Phase 2: lane
+// `fk_slot` sums the modes carrying its (sample, k, sin|cos) in mode order
+// (modes are stored sorted by k, ddd_set_forcing, so the run is contiguous).
+// Returns that sum; the caller publishes it to Shared::fk at the start of the
+// evaluation that uses it.  Must be called by all threads (one barrier).
+template <int kRows, int kWR>
+__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
+                                              const Resident& res, float t, int tid) {
+  const int spg = kRows / p.N;
+  // this lane's run of modes [m0, m1): constant over the launch, fetched first
+  // so the LDS round trip hides behind the sincos arithmetic
+  const bool summing = tid < spg * p.n_k * 2;
+  const int which = tid & 1;
+  const int sl = summing ? row_sample(tid >> 1, 1.0f / (float)p.n_k) : 0;   // exact
+  const int kk = summing ? (tid >> 1) - sl * p.n_k : 0;
+  const int m0 = sm.ks[sl * 8 + kk], m1 = summing ? (int)sm.ks[sl * 8 + kk + 1] : 0;
+  if (tid < spg * p.P) {
+    float sn, cs;
+    sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
+    sm.pm[tid] = make_float2(res.frc_a * sn, res.frc_a * cs);
+  }
+  __syncthreads();
+  float acc = 0.0f;
+  if (summing) {
+    const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm + sl * p.P) + which;
+    const int last = p.P - 1;
+    // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
+    // entries past the run add an exact 0, so the sum keeps mode order
+    for (int m = m0; m < m1; m += 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = pm[2 * min(m + i, last)];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = acc + (m + i < m1 ? v[i] : 0.0f);
+    }
+  }
+  return acc;
+}
 
 // One evaluation of finalize_time_derivative(t, predict_time_derivative(u))
 // for the workgroup's rows.  Must be called by all kRows threads.
@@ -383,14 +469,25 @@ struct Resident {
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
-template <int kRows, int kWR, bool kHoist>
+template <int kRows, int kWR, bool kHoist, int kEq>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
-                                          float u, float t, Resident& res,
+                                          float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
                                           unsigned long long* trace = nullptr) {
 #define DDD_STAMP(i) do { if (trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
+  // run-time parameters, or compile-time constants when specialised (kEq >= 0)
+  constexpr bool kSpec = kEq >= 0;
+  const int eqn = kSpec ? kEq : p.equation;
+  const int nD = kSpec ? spec_derivs(kEq) : p.D;
+  const int nG = kSpec ? spec_stencil(kEq) : p.G;
+  const bool flux_form = kSpec ? spec_flux_form(kEq) : (p.conservative != 0);
+  const bool fixed = kSpec ? false : (p.fixed != 0);
+  const bool folded = kSpec ? (spec_derivs(kEq) <= 2) : (p.folded != 0);
+  const int act = kSpec ? (int)ACT_RELU : p.act;
+  const int nL = kHoist ? 3 : p.L;
+  const bool pow2 = (p.N & (p.N - 1)) == 0;   // wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
   const int tid = opaque((int)threadIdx.x);
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid);
@@ -399,7 +496,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][kKW];
   int fin_rows[4][kKW];     // same for the output layer's four 16-row tiles
-  if (!p.fixed) {
+  if (!fixed) {
 #pragma unroll
     for (int t2 = 0; t2 < kWR / 32; ++t2)
       tap_rows(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
@@ -407,32 +504,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     for (int t2 = 0; t2 < kWR / 16; ++t2)
       tap_rows(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
   }
-  if (!p.fixed && ln.owner) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
-  const int spg = kRows / p.N;
-  if (p.forced && fast_forcing && !(ablate & 1) && tid < spg * p.P) {
-    // forcing, phase 1: one (sample, mode) pair per lane.
-    //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
-    //     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
-    //   psi_j = omega_j t + phi_j,  theta_j(x) = 2 pi k_j x / L  (<= 6 distinct k)
-    float sn, cs;
-    sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
-    const float2 v = make_float2(res.frc_a * sn, res.frc_a * cs);
-    sm.pm[tid] = v;
-  }
+  if (!fixed && ln.owner) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
+  // harmonic forcing sums of THIS evaluation's time: computed during the
+  // previous evaluation (or the launch prologue), published here
+  // (after the barrier: slower wavefronts may still be reading sm.fk in the
+  // epilogue of the previous evaluation; the next barrier orders the readers)
   __syncthreads();
-  if (p.forced && fast_forcing && !(ablate & 1) && tid < spg * p.n_k * 2) {
-    // phase 2: per (sample, k, sin|cos) sum over the modes carrying that k.
-    // Modes are stored sorted by k (ddd_set_forcing), so the run is contiguous.
-    const int which = tid & 1;
-    const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
-    const int kk = (tid >> 1) - sl * p.n_k;
-    const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
-    float acc = 0.0f;
-    for (int m = m0; m < m1; ++m) {
-      const float2 v = sm.pm[sl * p.P + m];
-      acc = acc + (which ? v.y : v.x);
-    }
-    sm.fk[sl * kTrigMax + 2 * kk + which] = acc;
+  const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
+  if (p.forced && fast_forcing) {
+    const int slot = fk_slot_of(p, tid, kRows / p.N);
+    if (slot >= 0) sm.fk[slot] = res.fk_next;
   }
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
@@ -440,20 +521,21 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // they enter the next evaluation); a one-wave group reads them in the
   // epilogue instead and saves 8 registers across the conv tower.
   float pch[kGMax];
-  const int gl = p.G >> 1;
+  const int gl = nG >> 1;
   if (!kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
+      pch[g] = (g < nG) ? sm.u[pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                    : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
 
   float net[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) net[c] = 0.0f;
-  if (!p.fixed) {
+  if (!fixed) {
     float wfin[kFinSteps];
     DDD_STAMP(1);
-    if (!(ablate & 16)) input_layer<kWR>(p, ln, sm.un, sm.hA, res.w_in, hid_rows);
+    if (!(ablate & 16)) input_layer<kWR>(p, ln, sm.un, sm.hA, res.w_in, hid_rows, act);
     {   // first taps of the output layer: in flight while the hidden layers run
       const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
 #pragma unroll
@@ -461,10 +543,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     }
     float* in = sm.hA;
     float* out = sm.hB;
-    for (int l = 1; l < p.L - 1; ++l) {
+    for (int l = 1; l < nL - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
       __syncthreads();
-      hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows);
+      hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act);
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
@@ -473,6 +555,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
       for (int s2 = kFinPrefetch; s2 < kFinSteps; ++s2) wfin[s2] = wsrc[s2 * 64];
     }
+    // the output layer's weights are in flight from L2 and the hidden layer's
+    // last activations on their way to LDS: fill the wait with the forcing
+    // sums the next evaluation needs
+    if (p.forced && fast_forcing && !(ablate & 65))
+      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
     __syncthreads();
     final_layer<kWR>(p, ln, in, out, wfin, fin_rows);
     DDD_STAMP(3);
@@ -485,6 +572,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       net[4 * q + 2] = v.z; net[4 * q + 3] = v.w;
     }
   } else {
+    if (p.forced && fast_forcing && !(ablate & 65))
+      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
     __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
   }
 
@@ -499,26 +588,35 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // the epilogue, consumed by its last statement
   float4 trig4[kTrigMax / 4];
   if (p.forced && fast_forcing) {
-    const float4* __restrict__ tr =
-        reinterpret_cast<const float4*>(p.trig) + (size_t)opaque(ln.pos) * (kTrigMax / 4);
+    if (trig_lds) {
+      // <= 4 wavenumbers: the table sits in the four padding floats of this
+      // row in each activation buffer (launch_setup), never overwritten
+      trig4[0] = *reinterpret_cast<const float4*>(sm.hA + ln.row * kHS + 32);
+      trig4[1] = *reinterpret_cast<const float4*>(sm.hB + ln.row * kHS + 32);
+      trig4[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+      const float4* __restrict__ tr =
+          reinterpret_cast<const float4*>(p.trig) + (size_t)opaque(ln.pos) * (kTrigMax / 4);
 #pragma unroll
-    for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = tr[i];
+      for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = tr[i];
+    }
   }
   if (kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < p.G) ? sm.u[wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
+      pch[g] = (g < nG) ? sm.u[pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                    : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
   float cf[kMaxDerivs][kGMax];
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d)
 #pragma unroll
     for (int g = 0; g < kGMax; ++g) cf[d][g] = 0.0f;
-  if (!p.fixed && p.folded) {
+  if (!fixed && folded) {
     // the output layer already applied the projection: channel 8 d + g
 #pragma unroll
     for (int g = 0; g < kGMax; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
-  } else if (!p.fixed && !(ablate & 2)) {
+  } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       if (!((p.dsel_valid >> c) & 1u)) continue;
@@ -546,13 +644,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d) {
     dv[d] = 0.0f;
-    if (d < p.D) {
+    if (d < nD) {
 #pragma unroll
       for (int g = 0; g < kGMax; ++g) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
       if (coeffs_out != nullptr && ln.active) {
-        float* dst = coeffs_out + ((size_t)ln.gidx * p.D + d) * p.G;
+        float* dst = coeffs_out + ((size_t)ln.gidx * nD + d) * nG;
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (g < p.G) dst[g] = cf[d][g];
+        for (int g = 0; g < kGMax; ++g) if (g < nG) dst[g] = cf[d][g];
       }
       float s = 0.0f;
 #pragma unroll
@@ -563,17 +661,18 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (derivs_out != nullptr && ln.active) {
 #pragma unroll
     for (int d = 0; d < kMaxDerivs; ++d)
-      if (d < p.D) derivs_out[(size_t)ln.gidx * p.D + d] = dv[d];
+      if (d < nD) derivs_out[(size_t)ln.gidx * nD + d] = dv[d];
   }
 
   // ---- equation of motion ------------------------------------------------------
-  float r = equation_rhs_or_flux(p.equation, u, dv, p.eta);
-  if (p.conservative) {
+  float r = equation_rhs_or_flux(eqn, u, dv, p.eta);
+  if (flux_form) {
     float fnext;
     if (kOneWave) {
       // whole samples live in this wavefront: the right neighbour's flux comes
       // straight from its lane
-      fnext = __shfl(r, wrap_row(ln.base, ln.pos, 1, p.N), 64);
+      fnext = __shfl(r, pow2 ? (((ln.pos + 1) & (p.N - 1)) | ln.base)
+                                  : wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
       if (ln.owner) sm.flux[ln.row] = r;
       __syncthreads();
@@ -590,6 +689,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
+        if (i == 2 && trig_lds) break;   // entries 8..11 are zero padding
         const float4 f = fk4[i];
         total = fmaf(f.x, trig4[i].x, total);
         total = fmaf(f.y, trig4[i].y, total);
@@ -627,6 +727,14 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
+  res.fk_next = 0.0f;
+  if (fast && p.n_k <= 4 && ln.owner) {
+    // cos/sin of this grid point's spatial phases -> the row padding
+    const float4* __restrict__ tr =
+        reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
+    *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = tr[0];
+    *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = tr[1];
+  }
   for (int i = tid; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
   if (fast && tid < spg * p.P) {
     const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
@@ -648,7 +756,10 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
       }
     }
   }
-  return fast;   // visibility of sm.ks: the first __syncthreads() of eval_rhs
+  if (fast) {
+    __syncthreads();   // sm.ks visible to forcing_sums
+  }
+  return fast;
 }
 
 // ---------------------------------------------------------------------------
@@ -663,8 +774,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
-  const float f = eval_rhs<kRows, kWR, false>(p, sm, a.batch, u, (float)a.t, res,
-                                              fast_frc, a.derivs_out, a.coeffs_out);
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
+  const float f = eval_rhs<kRows, kWR, false, -1>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
+                                              fast_frc, a.derivs_out, a.coeffs_out, 64);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
     const float cf = a.c1 * f;
@@ -681,7 +793,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-template <int kRows, int kWR, typename ST, bool kHoist>
+template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
                                                                         IntegrateArgs a) {
   __shared__ Shared<kRows, kWR> sm;
@@ -714,6 +826,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
   int until_save = a.save_every;
   size_t snap = 0;
   int evals = 0;
+  if (fast_frc && !(ablate & 1))
+    res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
+                                           threadIdx.x);
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
     ST ynew = y;
@@ -725,8 +840,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       if (a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
         tr = a.trace + (size_t)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
-      const float f = eval_rhs<kRows, kWR, kHoist>(p, sm, a.batch, (float)us,
-                                              (float)(t + a.tab.c[s] * a.dt), res,
+      // time of the evaluation after this one (next stage, or stage 0 of the
+      // next step): its forcing sums are prepared inside this evaluation
+      const double tn = s + 1 < a.tab.stages
+                            ? t + a.tab.c[s + 1] * a.dt
+                            : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
+      const float f = eval_rhs<kRows, kWR, kHoist, kEq>(p, sm, a.batch, (float)us,
+                                              (float)(t + a.tab.c[s] * a.dt), (float)tn, res,
                                               fast_frc, nullptr, nullptr, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
