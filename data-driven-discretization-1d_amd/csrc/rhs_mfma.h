@@ -237,9 +237,11 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 // Input layer 1 -> 32 for this wave's two 32-row tiles (3 MFMA steps each).
 //   A: lane l supplies W1[out = l & 31][k = 2 s + (l >> 5)]  (k = tap; k = 5: bias)
 //   B: lane l supplies un[(pos(l & 31) + k - 2) mod N], un = u / std   (k = 5: 1.0)
-template <int kWR>
+// kShfl (one-wave groups: row == lane): operands come from the lanes' `un`
+// registers by ds_bpermute instead of an LDS write + read round trip.
+template <int kWR, bool kShfl>
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
-                                            const float* __restrict__ us,
+                                            const float* __restrict__ us, float un,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps],
                                             const int (&rows)[2][kKW], int act) {
@@ -249,9 +251,13 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
   f32x16 acc[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
-    const float b0 = us[half ? rows[t][1] : rows[t][0]];        // taps 0 / 1
-    const float b1 = us[half ? rows[t][3] : rows[t][2]];        // taps 2 / 3
-    const float b2 = half ? 1.0f : us[rows[t][4]];              // tap 4 / bias row
+    const int r0 = half ? rows[t][1] : rows[t][0];              // taps 0 / 1
+    const int r1 = half ? rows[t][3] : rows[t][2];              // taps 2 / 3
+    const int r2 = rows[t][4];                                  // tap 4 / bias row
+    const float b0 = kShfl ? __shfl(un, r0, 64) : us[r0];
+    const float b1 = kShfl ? __shfl(un, r1, 64) : us[r1];
+    const float v2 = kShfl ? __shfl(un, r2, 64) : us[r2];
+    const float b2 = half ? 1.0f : v2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     acc[t] = DDD_MFMA32(w[0], b0, acc[t]);
@@ -408,6 +414,7 @@ struct Resident {
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
+  int frc_run;              // its run of modes: (float offset into Shared::pm) | count << 16
 };
 
 // Index in Shared::fk of the harmonic sum lane `tid` carries: (sample, k,
@@ -423,43 +430,46 @@ __device__ __forceinline__ int fk_slot_of(const DevParams& p, int tid, int spg) 
 //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
 //     = sum_j [a_j sin(psi_j)] cos(theta_j(x)) + [a_j cos(psi_j)] sin(theta_j(x)),
 //   psi_j = omega_j t + phi_j,  theta_j(x) = 2 pi k_j x / L  (<= 6 distinct k).
-// Phase 1: one (sample, mode) pair per lane -> Shared::pm.  Phase 2: lane
-// `fk_slot` sums the modes carrying its (sample, k, sin|cos) in mode order
-// (modes are stored sorted by k, ddd_set_forcing, so the run is contiguous).
-// Returns that sum; the caller publishes it to Shared::fk at the start of the
-// evaluation that uses it.  Must be called by all threads (one barrier).
+// Phase 1: one (sample, mode) pair per lane -> Shared::pm.  A barrier.  Phase
+// 2: lanes carrying a (sample, k, sin|cos) slot sum the modes with that k in
+// mode order (modes are stored sorted by k, ddd_set_forcing, so the run is
+// contiguous; Resident::frc_run).  The caller publishes the sum to Shared::fk
+// at the start of the evaluation that uses it.  Inside an evaluation the two
+// phases sit at the input->hidden and hidden->output layer boundaries, where
+// the wavefront otherwise only waits for its activations to land in LDS.
 template <int kRows, int kWR>
-__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
-                                              const Resident& res, float t, int tid) {
-  const int spg = kRows / p.N;
-  // this lane's run of modes [m0, m1): constant over the launch, fetched first
-  // so the LDS round trip hides behind the sincos arithmetic
-  const bool summing = tid < spg * p.n_k * 2;
-  const int which = tid & 1;
-  const int sl = summing ? row_sample(tid >> 1, 1.0f / (float)p.n_k) : 0;   // exact
-  const int kk = summing ? (tid >> 1) - sl * p.n_k : 0;
-  const int m0 = sm.ks[sl * 8 + kk], m1 = summing ? (int)sm.ks[sl * 8 + kk + 1] : 0;
-  if (tid < spg * p.P) {
+__device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR>& sm,
+                                               const Resident& res, float t, int tid) {
+  if (tid < (kRows / p.N) * p.P) {
     float sn, cs;
     sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
     sm.pm[tid] = make_float2(res.frc_a * sn, res.frc_a * cs);
   }
-  __syncthreads();
+}
+
+template <int kRows, int kWR>
+__device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Resident& res) {
+  const int cnt = res.frc_run >> 16;
+  const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm) + (res.frc_run & 0xffff);
   float acc = 0.0f;
-  if (summing) {
-    const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm + sl * p.P) + which;
-    const int last = p.P - 1;
-    // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
-    // entries past the run add an exact 0, so the sum keeps mode order
-    for (int m = m0; m < m1; m += 8) {
-      float v[8];
+  // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
+  // entries past the run add an exact 0, so the sum keeps mode order
+  for (int m = 0; m < cnt; m += 8) {
+    float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = pm[2 * min(m + i, last)];
+    for (int i = 0; i < 8; ++i) v[i] = pm[2 * min(m + i, cnt - 1)];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc = acc + (m + i < m1 ? v[i] : 0.0f);
-    }
+    for (int i = 0; i < 8; ++i) acc = acc + (m + i < cnt ? v[i] : 0.0f);
   }
   return acc;
+}
+
+template <int kRows, int kWR>
+__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
+                                              const Resident& res, float t, int tid) {
+  forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
+  __syncthreads();
+  return forcing_phase2<kRows, kWR>(sm, res);
 }
 
 // One evaluation of finalize_time_derivative(t, predict_time_derivative(u))
@@ -504,7 +514,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     for (int t2 = 0; t2 < kWR / 16; ++t2)
       tap_rows(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
   }
-  if (!fixed && ln.owner) sm.un[ln.row] = u / p.stddev;   // model.py:450-451, a true division
+  const float un_reg = u / p.stddev;   // model.py:450-451, a true division
+  // (a one-wave group feeds the input layer by lane permutes, not through LDS)
+  if (!fixed && !kOneWave && ln.owner) sm.un[ln.row] = un_reg;
   // harmonic forcing sums of THIS evaluation's time: computed during the
   // previous evaluation (or the launch prologue), published here
   // (after the barrier: slower wavefronts may still be reading sm.fk in the
@@ -535,7 +547,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (!fixed) {
     float wfin[kFinSteps];
     DDD_STAMP(1);
-    if (!(ablate & 16)) input_layer<kWR>(p, ln, sm.un, sm.hA, res.w_in, hid_rows, act);
+    if (!(ablate & 16))
+      input_layer<kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act);
+    const bool frc_next = p.forced && fast_forcing && !(ablate & 65);
+    if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     {   // first taps of the output layer: in flight while the hidden layers run
       const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
 #pragma unroll
@@ -558,8 +573,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     // the output layer's weights are in flight from L2 and the hidden layer's
     // last activations on their way to LDS: fill the wait with the forcing
     // sums the next evaluation needs
-    if (p.forced && fast_forcing && !(ablate & 65))
-      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
+    if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
+    if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
     __syncthreads();
     final_layer<kWR>(p, ln, in, out, wfin, fin_rows);
     DDD_STAMP(3);
@@ -756,8 +771,15 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
       }
     }
   }
+  res.frc_run = 0;
   if (fast) {
-    __syncthreads();   // sm.ks visible to forcing_sums
+    __syncthreads();   // sm.ks visible
+    if (tid < spg * p.n_k * 2) {
+      const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
+      const int kk = (tid >> 1) - sl * p.n_k;
+      const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
+      res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16);
+    }
   }
   return fast;
 }
