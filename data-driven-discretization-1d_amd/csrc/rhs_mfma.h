@@ -415,16 +415,8 @@ struct Resident {
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
   int frc_run;              // its run of modes: (float offset into Shared::pm) | count << 16
+                            // | (index of the sum in Shared::fk) << 24; 0: lane carries none
 };
-
-// Index in Shared::fk of the harmonic sum lane `tid` carries: (sample, k,
-// sin|cos) = (tid / (2 n_k), (tid / 2) % n_k, tid & 1); -1 for other lanes.
-__device__ __forceinline__ int fk_slot_of(const DevParams& p, int tid, int spg) {
-  if (tid >= spg * p.n_k * 2) return -1;
-  const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
-  const int kk = (tid >> 1) - sl * p.n_k;
-  return sl * kTrigMax + 2 * kk + (tid & 1);
-}
 
 // Forcing, phases 1 + 2, for time t:
 //   sum_j a_j sin(omega_j t + theta_j(x) + phi_j)
@@ -449,7 +441,7 @@ __device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows,
 
 template <int kRows, int kWR>
 __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Resident& res) {
-  const int cnt = res.frc_run >> 16;
+  const int cnt = (res.frc_run >> 16) & 0xff;
   const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm) + (res.frc_run & 0xffff);
   float acc = 0.0f;
   // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
@@ -523,10 +515,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // epilogue of the previous evaluation; the next barrier orders the readers)
   __syncthreads();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
-  if (p.forced && fast_forcing) {
-    const int slot = fk_slot_of(p, tid, kRows / p.N);
-    if (slot >= 0) sm.fk[slot] = res.fk_next;
-  }
+  if (p.forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
+    sm.fk[(unsigned)res.frc_run >> 24] = res.fk_next;
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
   // Four-wave groups must read them now (other waves rewrite sm.u as soon as
@@ -778,7 +768,8 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
       const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
       const int kk = (tid >> 1) - sl * p.n_k;
       const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
-      res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16);
+      res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
+                    ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
     }
   }
   return fast;
