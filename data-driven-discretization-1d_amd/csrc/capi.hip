@@ -18,6 +18,7 @@
 #include "ops.h"
 #include "rhs_generic.h"
 #include "rhs_mfma.h"
+#include "rhs_stream.h"
 
 namespace {
 
@@ -121,6 +122,8 @@ struct ddd_model {
   std::string mfma_reason;
   int kernel = DDD_KERNEL_GENERIC;   // resolved family
   int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
+  bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
+  const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
@@ -375,9 +378,34 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   return {64, 64};
 }
 
+bool aligned16(const void* ptr) {
+  return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0;
+}
+
+// Fixed-stencil models without forcing: the streaming kernel (rhs_stream.h).
+bool use_stream_kernel(const ddd_model* m, const ddd::SubstepArgs& a) {
+  if (!ddd::stream::supports(m->dp) || m->explicit_kernel) return false;
+  if (a.derivs_out != nullptr || a.coeffs_out != nullptr) return false;
+  const char* off = std::getenv("DDD_NO_STREAM");
+  if (off != nullptr && off[0] == '1') return false;
+  return aligned16(a.y_in) && aligned16(a.y_base) && aligned16(a.y_out) &&
+         aligned16(a.acc_in) && aligned16(a.acc_out);
+}
+
 int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
   if (a.batch == 0) return DDD_OK;
   m->last_batch = a.batch;
+  if (use_stream_kernel(m, a)) {
+    const long pts = (long)ddd::stream::samples_per_block(m->dp.N) * m->dp.N;
+    const long total = (long)a.batch * m->dp.N;
+    const unsigned blocks = (unsigned)((total + pts - 1) / pts);
+    hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel, dim3(blocks),
+                       dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
+    m->last_substep_kernel = "stream_fixed";
+    DDD_HIP(hipGetLastError());
+    return DDD_OK;
+  }
+  m->last_substep_kernel = m->kernel == DDD_KERNEL_MFMA ? "mfma" : "generic";
   if (m->kernel == DDD_KERNEL_MFMA) {
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     const int spg = geo.rows / m->dp.N;
@@ -646,7 +674,8 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
   m->dp.bias = m->d_bias;
   if (!rc) {
     decide_mfma(m);
-    if (m->mfma_ok) rc = upload_padded_tables(m, nullptr, stencils);
+    // the padded stencil table also feeds the streaming kernel (any N <= 1024)
+    if (m->mfma_ok || m->dp.G <= ddd::kGMax) rc = upload_padded_tables(m, nullptr, stencils);
   }
   if (rc) { ddd_model_destroy(m); return rc; }
   *out = m;
@@ -907,9 +936,11 @@ int ddd_set_kernel(ddd_model* m, int kind) {
     case DDD_KERNEL_AUTO:
       m->kernel = m->mfma_ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;
       m->force_rows = 0;
+      m->explicit_kernel = false;
       return DDD_OK;
     case DDD_KERNEL_GENERIC:
       m->kernel = DDD_KERNEL_GENERIC;
+      m->explicit_kernel = true;
       return DDD_OK;
     case DDD_KERNEL_MFMA:
     case DDD_KERNEL_MFMA_ROWS64:
@@ -923,6 +954,7 @@ int ddd_set_kernel(ddd_model* m, int kind) {
         return fail(DDD_ERR_UNSUPPORTED,
                     "64-row workgroups need num_points to divide 64 (got %d)", m->dp.N);
       m->kernel = DDD_KERNEL_MFMA;
+      m->explicit_kernel = true;
       m->force_rows = kind == DDD_KERNEL_MFMA_ROWS64 ? 64
                       : kind == DDD_KERNEL_MFMA_ROWS64_W32 ? 32
                       : kind == DDD_KERNEL_MFMA_ROWS256 ? 256 : 0;
@@ -941,6 +973,12 @@ const char* ddd_kernel_name(const ddd_model* m) {
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
+
+// Name of the kernel the most recent fused-substep launch of this model used
+// ("stream_fixed", "mfma", "generic"; "" before the first launch).  Tests only.
+const char* ddd_debug_last_substep_kernel(const ddd_model* m) {
+  return m != nullptr ? m->last_substep_kernel : "";
+}
 
 int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
   unsigned* d = nullptr;

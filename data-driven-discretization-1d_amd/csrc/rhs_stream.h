@@ -1,0 +1,110 @@
+// Streaming fused RK substep for FIXED-stencil models (ddd_baseline_create):
+//   model.baseline_space_derivatives  model.py:59-112   (explicit accuracy_order)
+//   model.apply_space_derivatives     model.py:115-135
+//   integrate.PolynomialDifferentiator integrate.py:74-105
+// With one launch per substep this is the only HBM-shaped kernel of the path
+// (~20 FMA against 8-12 B per grid point), so it is written as a stream: each
+// thread owns four consecutive grid points (one float4 per array), a block
+// stages 1024 points (whole samples) in LDS for the periodic stencil reads,
+// and the grid is batch * N / 1024 blocks -- no per-sample workgroup setup.
+// Unforced equations only (KdV, KS, unforced Burgers); forced or odd-sized
+// cases keep the per-sample kernels (rhs_mfma.h / rhs_generic.h).
+#pragma once
+#include "dev_params.h"
+
+namespace ddd {
+namespace stream {
+
+constexpr int kThreads = 256;
+constexpr int kPer = 4;                       // consecutive grid points per thread
+constexpr int kTilePoints = kThreads * kPer;  // grid points per block
+constexpr int kWin = kPer + 1 + kGMax - 1;    // stencil window of one thread (flux form: +1)
+
+__host__ __device__ inline int samples_per_block(int n) { return kTilePoints / n; }
+
+// The configurations this kernel covers (checked on the host before launch).
+inline bool supports(const DevParams& p) {
+  return p.fixed && !p.forced && p.N >= 8 && p.N <= kTilePoints && p.N % kPer == 0 &&
+         p.G <= kGMax;
+}
+
+__global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, SubstepArgs a) {
+  __shared__ float tile[kTilePoints];
+  const int n = p.N;
+  const int pts = samples_per_block(n) * n;                 // multiple of 4, <= 1024
+  const long base = (long)blockIdx.x * pts;
+  const long total = (long)a.batch * n;
+  const long rest = total - base;
+  const int live = rest < (long)pts ? (int)rest : pts;      // whole samples
+  const int i0 = threadIdx.x * kPer;
+  if (i0 < live)
+    *reinterpret_cast<float4*>(tile + i0) = *reinterpret_cast<const float4*>(a.y_in + base + i0);
+  __syncthreads();
+  if (i0 >= live) return;
+
+  const int s0 = (i0 / n) * n;     // first point of this thread's sample inside the tile
+  const int pos0 = i0 - s0;        // its four points are pos0 .. pos0 + 3 (N % 4 == 0)
+  const int gl = p.G >> 1;         // patches[i] = u[(x + i - G/2) mod N]  (model.py:516-533)
+  float w[kWin];
+#pragma unroll
+  for (int j = 0; j < kWin; ++j) {
+    int q = pos0 - gl + j;         // in (-N, 2N): one conditional wrap each way
+    q = q < 0 ? q + n : q;
+    q = q >= n ? q - n : q;
+    w[j] = tile[s0 + q];
+  }
+  // the points themselves (window entry gl + q, read directly: gl is a run-time value)
+  const float4 own = *reinterpret_cast<const float4*>(tile + i0);
+  const int qn = pos0 + kPer >= n ? pos0 + kPer - n : pos0 + kPer;
+  const float uc[kPer + 1] = {own.x, own.y, own.z, own.w, tile[s0 + qn]};
+  // u_t (plain forms) or the flux (flux forms; one extra point for the
+  // staggered difference, equations.staggered_first_derivative)
+  float f[kPer + 1];
+#pragma unroll
+  for (int q = 0; q < kPer + 1; ++q) {
+    f[q] = 0.0f;
+    if (q < kPer || p.conservative) {
+      float dv[kMaxDerivs];
+#pragma unroll
+      for (int d = 0; d < kMaxDerivs; ++d) {
+        float s = 0.0f;
+        if (d < p.D) {
+#pragma unroll
+          for (int g = 0; g < kGMax; ++g) s = fmaf(p.bias8[d][g], w[q + g], s);
+        }
+        dv[d] = s;
+      }
+      f[q] = equation_rhs_or_flux(p.equation, uc[q], dv, p.eta);
+    }
+  }
+  float r[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q)
+    r[q] = p.conservative ? -(p.inv_dx * (f[q + 1] - f[q])) : f[q];
+
+  const long gi = base + i0;
+  if (a.y_out != nullptr) {
+    float4 o = make_float4(a.c1 * r[0], a.c1 * r[1], a.c1 * r[2], a.c1 * r[3]);
+    if (a.y_base != nullptr) {
+      // stage 0 reads y as both input and base: reuse the staged tile
+      const float4 b = a.y_base == a.y_in
+                           ? own
+                           : *reinterpret_cast<const float4*>(a.y_base + gi);
+      o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+    }
+    *reinterpret_cast<float4*>(a.y_out + gi) = o;
+  }
+  if (a.acc_out != nullptr) {
+    float4 o = make_float4(a.c2 * r[0], a.c2 * r[1], a.c2 * r[2], a.c2 * r[3]);
+    if (a.acc_in != nullptr) {
+      const float4 b = a.acc_in == a.y_in
+                           ? own
+                           : *reinterpret_cast<const float4*>(a.acc_in + gi);
+      o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+    }
+    *reinterpret_cast<float4*>(a.acc_out + gi) = o;
+  }
+}
+
+}  // namespace stream
+}  // namespace ddd

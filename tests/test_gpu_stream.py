@@ -1,0 +1,113 @@
+"""Streaming fixed-stencil substep kernel (csrc/rhs_stream.h): the HBM-shaped
+variant of PolynomialDifferentiator / integrate_baseline
+(integrate.py:74-105, model.py:59-135) used with one launch per substep."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from helpers import oracle, random_phase_ic, batch_forcing, baseline_spec, rel_err
+from ddd1d_amd import equations, model as model_lib, _lib
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5   # float32 trajectories within 1e-5 rel of the oracle
+
+
+def last_substep_kernel(model):
+  lib = _lib.load_library()
+  lib.ddd_debug_last_substep_kernel.restype = ctypes.c_char_p
+  lib.ddd_debug_last_substep_kernel.argtypes = [ctypes.c_void_p]
+  return lib.ddd_debug_last_substep_kernel(model._handle).decode()
+
+
+def make_baseline(cls, n, rf=1, **kw):
+  eq = cls(n, resample_factor=rf, **kw)
+  return eq, model_lib.BaselineModel(eq, accuracy_order=1)
+
+
+CASES = [
+    (equations.KdVEquation, 64, 5, 2.5e-5),
+    (equations.ConservativeKdVEquation, 64, 37, 2.5e-5),    # ragged last block (16 samples/block)
+    (equations.KSEquation, 256, 9, 2.5e-5),
+    (equations.ConservativeKSEquation, 100, 23, 2.5e-5),    # N not a power of two: 10 samples/block
+    (equations.ConservativeKdVEquation, 32, 70, 2.5e-5),
+]
+
+
+@pytest.mark.parametrize('cls,n,batch,dt', CASES)
+def test_stream_kernel_matches_oracle_and_persistent(cls, n, batch, dt):
+  eq, model = make_baseline(cls, n)
+  y0 = random_phase_ic(eq, batch)
+  for scheme, sid in (('midpoint', oracle.SCHEME_MIDPOINT), ('bs3', oracle.SCHEME_BS3)):
+    got = model.integrate_fixed(y0, 20, dt=dt, scheme=scheme, save_every=5,
+                                launch_mode='per_substep').cpu().numpy()
+    assert last_substep_kernel(model) == 'stream_fixed'
+    want = oracle.integrate_fixed(baseline_spec(eq), sid, 0.0, dt, 20, 5, y0)
+    err = rel_err(got, want)
+    print(cls.__name__, n, scheme, 'rel err {:.2e}'.format(err))
+    assert err < TOL
+    if n <= 256:   # the persistent per-sample kernel: same arithmetic, same order
+      ref = model.integrate_fixed(y0, 20, dt=dt, scheme=scheme, save_every=5,
+                                  launch_mode='persistent').cpu().numpy()
+      np.testing.assert_array_equal(got, ref)
+
+
+def test_stream_kernel_one_sample_per_block():
+  """N = 1024 fills a block.  1/dx^3 = 3e4 amplifies float32 rounding of the
+  third-derivative stencil, so the bound is the float32 oracle's own distance
+  from a float64 evaluation of the same formulas (as for KS in test_gpu_rhs)."""
+  eq, model = make_baseline(equations.KdVEquation, 1024)
+  spec = baseline_spec(eq)
+  y = random_phase_ic(eq, 3)
+  got = model.time_derivative(y, 0.0).cpu().numpy()
+  assert last_substep_kernel(model) == 'stream_fixed'
+  y64 = y.astype(np.float64)
+  derivs = np.stack([
+      sum(float(np.float32(c)) * np.roll(y64, len(taps) // 2 - i, axis=1)
+          for i, c in enumerate(taps))
+      for taps in spec['baseline_coefficients']], axis=-1)   # layers.py:76-79 alignment
+  truth = oracle.equation_of_motion(spec['equation'], y64, derivs, spec['eta'], spec['dx'])
+  floor = rel_err(oracle.time_derivative(spec, 0.0, y), truth)
+  print('N=1024 float32 floor {:.2e}, stream kernel {:.2e}'.format(floor, rel_err(got, truth)))
+  assert rel_err(got, truth) < max(4 * floor, TOL)
+
+
+def test_stream_kernel_time_derivative_and_fallbacks():
+  eq, model = make_baseline(equations.ConservativeKdVEquation, 64)
+  y = random_phase_ic(eq, 11)
+  got = model.time_derivative(y, 0.0).cpu().numpy()
+  assert last_substep_kernel(model) == 'stream_fixed'
+  want = oracle.time_derivative(baseline_spec(eq), 0.0, y)
+  assert rel_err(got, want) < TOL
+  # explicit kernel choice keeps the per-sample kernels
+  model.set_kernel('generic')
+  same = model.time_derivative(y, 0.0).cpu().numpy()
+  assert last_substep_kernel(model) == 'generic'
+  np.testing.assert_allclose(same, got, rtol=0, atol=TOL * np.abs(want).max())
+  model.set_kernel('auto')
+  # derivative views are not the stream kernel's job
+  model.space_derivatives(y)
+  assert last_substep_kernel(model) == 'mfma'
+  # forced Burgers: per-sample kernel (harmonic forcing tables live there)
+  eqb, mb = make_baseline(equations.BurgersEquation, 64)
+  mb.set_forcing(batch_forcing(4))
+  mb.time_derivative(random_phase_ic(eqb, 4), 0.3)
+  assert last_substep_kernel(mb) == 'mfma'
+
+
+def test_stream_kernel_mean_conservation_full_size():
+  """Flux forms conserve the mean (integrate_test.py:101-104, 183-185) at a
+  batch that fills the GPU: 65 536 samples x 64 points, 50 midpoint steps."""
+  eq, model = make_baseline(equations.ConservativeKdVEquation, 64)
+  batch = 65536
+  y0 = np.tile(random_phase_ic(eq, 64), (batch // 64, 1))
+  out = model.integrate_fixed(y0, 50, dt=2.5e-5, save_every=50,
+                              launch_mode='per_substep')[0]
+  assert last_substep_kernel(model) == 'stream_fixed'
+  got = out.double().mean(dim=1).cpu().numpy()
+  assert np.isfinite(got).all()
+  np.testing.assert_allclose(got, y0.astype(np.float64).mean(axis=1), atol=1e-5)
+  # identical samples evolve identically wherever they sit in the batch
+  rows = out.cpu().numpy()
+  np.testing.assert_array_equal(rows[:64], rows[-64:])
