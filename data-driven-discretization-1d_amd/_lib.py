@@ -47,7 +47,8 @@ class DDDConfig(ctypes.Structure):
       ('polynomial_accuracy_order', ctypes.c_int32),
       ('ensure_unbiased_coefficients', ctypes.c_int32),
       ('input_sizes', ctypes.c_int32 * MAX_DERIVATIVES),
-      ('reserved', ctypes.c_int32 * 4),
+      ('weno_reconstruction', ctypes.c_int32),
+      ('reserved', ctypes.c_int32 * 3),
   ]
 
 
@@ -71,6 +72,9 @@ SIGNATURES = {
     'ddd_baseline_create': (ctypes.c_int, [ctypes.POINTER(DDDConfig), _F,
                                            ctypes.c_size_t,
                                            ctypes.POINTER(_V)]),
+    'ddd_spectral_create': (ctypes.c_int, [ctypes.POINTER(DDDConfig), _D,
+                                           ctypes.c_size_t,
+                                           ctypes.POINTER(_V)]),
     'ddd_model_destroy': (ctypes.c_int, [_V]),
     'ddd_set_forcing': (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int, _F, _F,
                                        _F, _I, _F, ctypes.c_int]),
@@ -89,6 +93,12 @@ SIGNATURES = {
                                                ctypes.c_double, ctypes.c_int,
                                                ctypes.c_int, _V, _V,
                                                ctypes.c_int, _V]),
+    'ddd_time_derivative_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
+                                               ctypes.c_int, _V]),
+    'ddd_rk_substep_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
+                                          ctypes.c_double, _V, _V,
+                                          ctypes.c_double, _V, ctypes.c_int,
+                                          _V]),
     'ddd_space_derivatives': (ctypes.c_int, [_V, _V, _V, ctypes.c_int, _V]),
     'ddd_coefficients': (ctypes.c_int, [_V, _V, _V, ctypes.c_int, _V]),
     'ddd_conv1d_periodic': (ctypes.c_int, [_V, _V, _V, _V, ctypes.c_int,

@@ -18,6 +18,7 @@
 #include "ops.h"
 #include "rhs_generic.h"
 #include "rhs_mfma.h"
+#include "rhs_spectral.h"
 #include "rhs_stream.h"
 
 namespace {
@@ -83,6 +84,18 @@ int expected_derivatives(int eq) {
   }
 }
 
+// b weights in float64 (the float32 tableau rounds 2/9, 1/3, 4/9, 1/6).
+void tableau_weights_f64(int scheme, double (&b)[ddd::kMaxStages]) {
+  for (double& v : b) v = 0.0;
+  switch (scheme) {
+    case DDD_SCHEME_EULER: b[0] = 1.0; break;
+    case DDD_SCHEME_MIDPOINT: b[1] = 1.0; break;
+    case DDD_SCHEME_BS3: b[0] = 2.0 / 9.0; b[1] = 1.0 / 3.0; b[2] = 4.0 / 9.0; break;
+    case DDD_SCHEME_RK4: b[0] = 1.0 / 6.0; b[1] = 1.0 / 3.0; b[2] = 1.0 / 3.0; b[3] = 1.0 / 6.0; break;
+    default: break;
+  }
+}
+
 int make_tableau(int scheme, ddd::Tableau* tab) {
   std::memset(tab, 0, sizeof(*tab));
   switch (scheme) {
@@ -136,6 +149,12 @@ struct ddd_model {
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
   float* d_trig = nullptr;
+  // spectral (float64) models: ddd_spectral_create
+  bool spectral = false;
+  ddd::spectral::Params sp{};
+  double* d_kernels = nullptr;
+  double* d_scratch64 = nullptr;
+  size_t scratch64_doubles = 0;
   // scratch for the per-substep launch mode
   float* d_scratch = nullptr;
   size_t scratch_floats = 0;
@@ -305,6 +324,7 @@ void decide_mfma(ddd_model* m) {
   auto no = [&](const char* msg) { if (ok) snprintf(why, sizeof(why), "%s", msg); ok = false; };
   if (dp.N < 8 || dp.N > 256) no("num_points outside [8, 256]");
   if (dp.G > ddd::kGMax) no("stencil wider than 8");
+  if (dp.fixed && dp.weno) no("WENO reconstruction");
   if (!dp.fixed) {
     if (dp.target != ddd::TARGET_COEFFICIENTS) no("model_target is not 'coefficients'");
     if (dp.pao <= 0) no("polynomial_accuracy_order is 0");
@@ -337,8 +357,12 @@ int ensure_scratch(ddd_model* m, size_t floats) {
   return DDD_OK;
 }
 
-int check_batch(const ddd_model* m, int batch) {
+int check_batch(const ddd_model* m, int batch, bool want_spectral = false) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (m->spectral != want_spectral)
+    return fail(DDD_ERR_UNSUPPORTED,
+                m->spectral ? "spectral (float64) models only accept the *_f64 entry points"
+                            : "this entry point needs a spectral model (ddd_spectral_create)");
   if (batch < 0) return fail(DDD_ERR_INVALID_ARGUMENT, "negative batch");
   if (m->dp.forced && batch > m->dp.forcing_batch)
     return fail(DDD_ERR_INVALID_ARGUMENT,
@@ -667,6 +691,12 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
   m->cfg = *cfg;
   fill_equation(*cfg, &m->dp);
   m->dp.fixed = 1;
+  m->dp.weno = cfg->weno_reconstruction != 0;
+  if (m->dp.weno && (cfg->num_derivatives < 2 || cfg->equation < DDD_EQ_BURGERS_GODUNOV)) {
+    delete m;
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "weno_reconstruction needs a Godunov-flux equation (u_minus, u_plus)");
+  }
   m->dp.stddev = 1.0f;
   m->fma_per_point = (int64_t)cfg->num_derivatives * cfg->stencil_size;
   std::vector<float> sv(stencils, stencils + n_stencils);
@@ -682,6 +712,85 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
   return DDD_OK;
 }
 
+int ddd_spectral_create(const ddd_config* cfg, const double* kernels, size_t n_kernels,
+                        ddd_model** out) {
+  if (out == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int rc = common_config_checks(cfg);
+  if (rc) return rc;
+  if (cfg->equation != DDD_EQ_BURGERS && cfg->equation != DDD_EQ_KDV &&
+      cfg->equation != DDD_EQ_KS)
+    return fail(DDD_ERR_UNSUPPORTED,
+                "spectral models exist for the non-flux equations only (integrate.py:346)");
+  if (cfg->num_points > ddd::spectral::kMaxPoints || cfg->num_points % 2)
+    return fail(DDD_ERR_UNSUPPORTED, "spectral models need an even num_points <= %d (got %d)",
+                ddd::spectral::kMaxPoints, cfg->num_points);
+  if (kernels == nullptr || n_kernels != (size_t)cfg->num_derivatives * cfg->num_points)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "kernels must hold D*N = %d doubles, got %zu",
+                cfg->num_derivatives * cfg->num_points, n_kernels);
+  ddd_model* m = new ddd_model();
+  m->cfg = *cfg;
+  fill_equation(*cfg, &m->dp);
+  m->spectral = true;
+  m->kernel = DDD_KERNEL_GENERIC;
+  m->mfma_reason = "spectral model";
+  m->fma_per_point = (int64_t)cfg->num_derivatives * cfg->num_points;
+  m->sp.equation = cfg->equation;
+  m->sp.N = cfg->num_points;
+  m->sp.D = cfg->num_derivatives;
+  m->sp.eta = cfg->eta;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_kernels), n_kernels * sizeof(double));
+  if (e == hipSuccess)
+    e = hipMemcpy(m->d_kernels, kernels, n_kernels * sizeof(double), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    ddd_model_destroy(m);
+    return fail(DDD_ERR_HIP, "spectral kernels upload: %s", hipGetErrorString(e));
+  }
+  m->sp.kernels = m->d_kernels;
+  *out = m;
+  return DDD_OK;
+}
+
+namespace {
+int launch_spectral(ddd_model* m, const ddd::spectral::SubstepArgs64& a, hipStream_t stream) {
+  if (a.batch == 0) return DDD_OK;
+  const size_t lds = ddd::spectral::lds_bytes(m->sp);
+  DDD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ddd::spectral::substep_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ddd::spectral::substep_kernel, dim3(a.batch),
+                     dim3(ddd::spectral::kThreads), lds, stream, m->sp, a);
+  DDD_HIP(hipGetLastError());
+  m->last_batch = a.batch;
+  return DDD_OK;
+}
+}  // namespace
+
+int ddd_time_derivative_f64(ddd_model* m, double t, const double* y, double* dydt, int batch,
+                            void* stream) {
+  (void)t;   // the equations of motion are autonomous; forcing stays on the host
+  int rc = check_batch(m, batch, true);
+  if (rc) return rc;
+  if (batch > 0 && (!y || !dydt)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  ddd::spectral::SubstepArgs64 a{};
+  a.y_in = y; a.c1 = 1.0; a.y_out = dydt; a.batch = batch;
+  return launch_spectral(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_rk_substep_f64(ddd_model* m, double t, const double* y_in, const double* y_base,
+                       double c1, double* y_out, const double* acc_in, double c2,
+                       double* acc_out, int batch, void* stream) {
+  (void)t;
+  int rc = check_batch(m, batch, true);
+  if (rc) return rc;
+  if (batch > 0 && !y_in) return fail(DDD_ERR_INVALID_ARGUMENT, "y_in is NULL");
+  if (batch > 0 && !y_out && !acc_out)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "both y_out and acc_out are NULL");
+  ddd::spectral::SubstepArgs64 a{};
+  a.y_in = y_in; a.y_base = y_base; a.c1 = c1; a.y_out = y_out;
+  a.acc_in = acc_in; a.c2 = c2; a.acc_out = acc_out; a.batch = batch;
+  return launch_spectral(m, a, static_cast<hipStream_t>(stream));
+}
+
 int ddd_model_destroy(ddd_model* m) {
   if (m == nullptr) return DDD_OK;
   free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
@@ -689,6 +798,8 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_w_input);
   free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   free_dev(m->d_scratch);
+  if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
+  if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
   delete m;
   return DDD_OK;
 }
@@ -707,6 +818,9 @@ int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude
                     const float* omega, const float* phase, const int32_t* k_index,
                     const float* spatial_phase, int n_k) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (m->spectral)
+    return fail(DDD_ERR_UNSUPPORTED,
+                "spectral models carry no forcing: apply finalize_time_derivative on the host");
   if (batch < 1 || nparams < 1 || n_k < 1)
     return fail(DDD_ERR_INVALID_ARGUMENT, "batch, nparams and n_k must be >= 1");
   if (!amplitude || !omega || !phase || !k_index || !spatial_phase)
@@ -870,6 +984,53 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
 int ddd_integrate_fixed_f64(ddd_model* m, int scheme, double t0, double dt, int n_steps,
                             int save_every, const double* y0, double* y_out, int batch,
                             void* stream) {
+  if (m != nullptr && m->spectral) {
+    // float64 state AND right-hand side, one fused launch per substep
+    if (batch < 0 || n_steps < 0 || save_every < 1)
+      return fail(DDD_ERR_INVALID_ARGUMENT, "bad batch / n_steps / save_every");
+    if (batch == 0 || n_steps == 0) return DDD_OK;
+    if (y0 == nullptr || y_out == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+    ddd::Tableau tab;
+    int rcs = make_tableau(scheme, &tab);
+    if (rcs) return rcs;
+    double b64[ddd::kMaxStages];
+    tableau_weights_f64(scheme, b64);
+    const size_t elems = (size_t)batch * m->sp.N;
+    if (m->scratch64_doubles < 3 * elems) {
+      if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
+      m->d_scratch64 = nullptr; m->scratch64_doubles = 0;
+      DDD_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_scratch64), 3 * elems * sizeof(double)));
+      m->scratch64_doubles = 3 * elems;
+    }
+    double* ping = m->d_scratch64;
+    double* pong = ping + elems;
+    double* ystage = ping + 2 * elems;
+    const double* y = y0;
+    size_t snap = 0;
+    for (int step = 0; step < n_steps; ++step) {
+      const bool saving = (step + 1) % save_every == 0;
+      double* ynew = saving ? y_out + snap * elems : (y == ping ? pong : ping);
+      const double* acc = nullptr;
+      for (int s = 0; s < tab.stages; ++s) {
+        ddd::spectral::SubstepArgs64 a{};
+        a.y_in = s == 0 ? y : ystage;
+        a.batch = batch;
+        const bool last = s == tab.stages - 1;
+        if (!last) { a.y_base = y; a.c1 = (double)tab.a[s + 1] * dt; a.y_out = ystage; }
+        if (tab.b[s] != 0.0f || last) {
+          a.acc_in = acc != nullptr ? acc : y;
+          a.c2 = b64[s] * dt;
+          a.acc_out = ynew;
+          acc = ynew;
+        }
+        rcs = launch_spectral(m, a, static_cast<hipStream_t>(stream));
+        if (rcs) return rcs;
+      }
+      y = ynew;
+      if (saving) ++snap;
+    }
+    return DDD_OK;
+  }
   int rc = check_integrate_args(m, n_steps, save_every, y0, y_out, batch);
   if (rc) return rc;
   ddd::IntegrateArgs a{};
@@ -932,6 +1093,7 @@ int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
 
 int ddd_set_kernel(ddd_model* m, int kind) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (m->spectral) return fail(DDD_ERR_UNSUPPORTED, "spectral models have one kernel");
   switch (kind) {
     case DDD_KERNEL_AUTO:
       m->kernel = m->mfma_ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;

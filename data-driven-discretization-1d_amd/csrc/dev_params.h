@@ -30,6 +30,7 @@ struct DevParams {
   int conservative;    // flux form: needs the staggered difference
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
+  int weno;            // fixed only: derivatives 0 / 1 are WENO5 reconstructions
   int target, L, F, K, act, C_out, pao, unbiased;
   int in_start[kMaxDerivs], in_size[kMaxDerivs], ns_off[kMaxDerivs];
   int w_off[kMaxLayers], b_off[kMaxLayers], cin[kMaxLayers], cout[kMaxLayers];
@@ -127,6 +128,70 @@ __device__ __forceinline__ void sincos_branchless(float x, float* s, float* c) {
   const float c0 = (q & 1) ? sr : cr;
   *s = (q & 2) ? -s0 : s0;
   *c = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// Fifth-order upwind-biased WENO reconstructions at the LEFT cell edge of grid
+// point `pos` (weno.py:43-123, rolled by one cell as integrate.py:137-138 and
+// model.py:82-88 do): *um = reconstruct_left(u)[pos - 1],
+// *up = reconstruct_right(u)[pos - 1].  `u` holds one periodic sample of n
+// points.  Arithmetic follows the reference's expression order in float32.
+__device__ __forceinline__ void weno_indicators(float m2, float m1, float c, float p1,
+                                                float p2, float (&is)[3]) {
+  // weno.calculate_smoothness_indicators, Equation (7) of Tang (2005)
+  const float a0 = (m2 - 4.0f * m1) + 3.0f * c, b0 = (m2 - 2.0f * m1) + c;
+  const float a1 = m1 - p1, b1 = (m1 - 2.0f * c) + p1;
+  const float a2 = (3.0f * c - 4.0f * p1) + p2, b2 = (c - 2.0f * p1) + p2;
+  const float q = 0.25f, r = (float)(13.0 / 12.0);
+  is[0] = q * (a0 * a0) + r * (b0 * b0);
+  is[1] = q * (a1 * a1) + r * (b1 * b1);
+  is[2] = q * (a2 * a2) + r * (b2 * b2);
+}
+
+__device__ __forceinline__ void weno_omega(const float (&is)[3], float w0, float w1,
+                                           float w2, float (&om)[3]) {
+  // weno.calculate_omega: alpha = w / (eps + IS)^2, omega = alpha / sum(alpha)
+  const float eps = 1e-6f;
+  const float d0 = eps + is[0], d1 = eps + is[1], d2 = eps + is[2];
+  const float al0 = w0 / (d0 * d0), al1 = w1 / (d1 * d1), al2 = w2 / (d2 * d2);
+  const float total = (al0 + al1) + al2;
+  om[0] = al0 / total; om[1] = al1 / total; om[2] = al2 / total;
+}
+
+__device__ __forceinline__ void weno_minus_plus(const float* u, int pos, int n,
+                                                float* um, float* up) {
+  float w[6];   // u[pos - 3 .. pos + 2]
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    int q = pos - 3 + j;
+    q = q < 0 ? q + n : q;
+    q = q >= n ? q - n : q;
+    w[j] = u[q];
+  }
+  float is[3], om[3];
+  // reconstruct_left at cell pos - 1: window pos-3 .. pos+1
+  weno_indicators(w[0], w[1], w[2], w[3], w[4], is);
+  weno_omega(is, 0.1f, 0.6f, 0.3f, om);
+  {
+    const float c0 = om[0] / 3.0f;
+    const float c1 = -(7.0f * om[0] + om[1]) / 6.0f;
+    const float c2 = ((11.0f * om[0] + 5.0f * om[1]) + 2.0f * om[2]) / 6.0f;
+    const float c3 = (2.0f * om[1] + 5.0f * om[2]) / 6.0f;
+    const float c4 = -om[2] / 6.0f;
+    *um = (((c0 * w[0] + c1 * w[1]) + c2 * w[2]) + c3 * w[3]) + c4 * w[4];
+  }
+  // reconstruct_right at cell pos - 1: indicators of cell pos (weights
+  // reversed, omega rolled by -1), window pos-2 .. pos+2
+  weno_indicators(w[1], w[2], w[3], w[4], w[5], is);
+  weno_omega(is, 0.3f, 0.6f, 0.1f, om);
+  {
+    const float o2 = om[0], o1 = om[1], o0 = om[2];
+    const float c0 = -o2 / 6.0f;
+    const float c1 = (5.0f * o2 + 2.0f * o1) / 6.0f;
+    const float c2 = ((2.0f * o2 + 5.0f * o1) + 11.0f * o0) / 6.0f;
+    const float c3 = -(o1 + 7.0f * o0) / 6.0f;
+    const float c4 = o0 / 3.0f;
+    *up = (((c0 * w[1] + c1 * w[2]) + c2 * w[3]) + c3 * w[4]) + c4 * w[5];
+  }
 }
 
 // Godunov flux for u^2/2 (equations.py:341-349).

@@ -141,6 +141,14 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
         if (derivs_out != nullptr)
           derivs_out[((size_t)sample * n + pos) * p.D + d] = s;
       }
+      if (p.fixed && p.weno) {
+        // WENODifferentiator / best WENO baseline: u_minus, u_plus replaced
+        weno_minus_plus(c.u, pos, n, &dv[0], &dv[1]);
+        if (derivs_out != nullptr) {
+          derivs_out[((size_t)sample * n + pos) * p.D + 0] = dv[0];
+          derivs_out[((size_t)sample * n + pos) * p.D + 1] = dv[1];
+        }
+      }
       r = equation_rhs_or_flux(p.equation, y, dv, p.eta);
     }
     if (needs_flux_diff) c.flux[pos] = r; else c.dy[pos] = r;

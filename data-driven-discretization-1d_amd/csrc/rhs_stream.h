@@ -24,7 +24,7 @@ __host__ __device__ inline int samples_per_block(int n) { return kTilePoints / n
 
 // The configurations this kernel covers (checked on the host before launch).
 inline bool supports(const DevParams& p) {
-  return p.fixed && !p.forced && p.N >= 8 && p.N <= kTilePoints && p.N % kPer == 0 &&
+  return p.fixed && !p.weno && !p.forced && p.N >= 8 && p.N <= kTilePoints && p.N % kPer == 0 &&
          p.G <= kGMax;
 }
 

@@ -84,3 +84,31 @@ RESAMPLE_FUNCS = {
     'mean': resample_mean,
     'subsample': subsample,
 }
+
+
+def spectral_derivative(x, order: int = 1, period: float = 2 * np.pi):
+  """Differentiate along the last axis with a Fourier transform.
+
+  duckarray.py:105-113 (NumPy branch); the rfft form keeps the Nyquist mode
+  for odd orders, unlike scipy.fftpack.diff.
+  """
+  x = np.asarray(x)
+  length = x.shape[-1]
+  if length % 2:
+    raise ValueError('spectral derivative only works for even length data')
+  c = 2 * np.pi * 1j / period
+  k = np.fft.rfftfreq(length, d=1 / length)
+  return np.fft.irfft((c * k) ** order * np.fft.rfft(x))
+
+
+def smoothing_filter(x, alpha: float = -np.log(1e-15), order: int = 2):
+  """Low-pass exponential filter (duckarray.py:116-128)."""
+  x = np.asarray(x)
+  length = x.shape[-1]
+  if length % 2:
+    raise ValueError('smoothing filter only works for even length data')
+  count = length // 2
+  eta = np.arange(count + 1) / count
+  sigma = np.exp(-alpha * eta ** (2 * order))
+  return np.fft.irfft(sigma * np.fft.rfft(x))
+

@@ -6,7 +6,12 @@ Mirror of ``pde_superresolution/integrate.py`` for the learned-stencil path:
   SavedModelDifferentiator       integrate.py:48-71   (HIP model instead of a TF session)
   PolynomialDifferentiator       integrate.py:74-105
   odeint                         integrate.py:143-169 (SciPy RK23, max_step 0.01)
-  integrate                      integrate.py:238-279
+  SpectralDifferentiator         integrate.py:108-121 (float64 circulant kernel)
+  WENODifferentiator             integrate.py:124-140
+  odeint_with_periodic_filtering integrate.py:172-212
+  exact_differentiator           integrate.py:215-235
+  integrate                      integrate.py:238-279 (warm-up + filtering)
+  integrate_exact / _weno / _spectral  integrate.py:282-341
   integrate_baseline             integrate.py:296-308
   integrate_model_from_warm_start integrate.py:399-427
 
@@ -17,12 +22,14 @@ per-sample loop (run_evaluation.py:152-174) becomes on one MI355X.
 Results are ``xarray.Dataset`` objects when xarray is importable, otherwise a
 ``Dataset`` stand-in exposing the same ``data_vars`` / ``coords`` mapping.
 """
+import functools
 import logging
 from typing import Optional, Tuple
 
 import numpy as np
 
 from . import _lib
+from . import duckarray
 from . import equations as equations_lib
 from . import hparams as hparams_lib
 from . import model as model_lib
@@ -122,6 +129,60 @@ class PolynomialDifferentiator(_HipDifferentiator):
             for i, name in enumerate(self.equation.DERIVATIVE_NAMES)}
 
 
+class SpectralDifferentiator(Differentiator):
+  """Derivatives from a spectral method, float64 (integrate.py:108-121).
+
+  Space derivatives and the equation of motion run on the GPU
+  (``model.SpectralModel``: the circulant form of ``scipy.fftpack.diff``);
+  ``finalize_time_derivative`` (the Burgers forcing) is applied on the host in
+  float64 exactly as the reference does.
+  """
+
+  def __init__(self, equation):
+    self.equation = equation
+    self.model = model_lib.SpectralModel(equation, convention='fftpack')
+    self._torch = _lib.require_gpu()
+
+  def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
+    y64 = np.ascontiguousarray(np.asarray(y, dtype=np.float64)[np.newaxis, :])
+    time_derivative = self.model.time_derivative(y64, t)[0].cpu().numpy()
+    return self.equation.finalize_time_derivative(t, time_derivative)
+
+
+class WENODifferentiator(_HipDifferentiator):
+  """Fifth-order WENO for the Godunov-flux equations (integrate.py:124-140).
+
+  ``u_minus`` / ``u_plus`` are WENO5 reconstructions, every other derivative a
+  polynomial stencil of ``non_weno_accuracy_order``; Godunov flux, staggered
+  difference and forcing follow -- all in one kernel (rhs_generic.h).
+  """
+
+  def __init__(self, equation, non_weno_accuracy_order: int = 3):
+    if not ('u_minus' in equation.DERIVATIVE_NAMES and
+            'u_plus' in equation.DERIVATIVE_NAMES):
+      raise AssertionError('WENO needs u_minus and u_plus (integrate.py:136)')
+    model = model_lib.BaselineModel(equation, non_weno_accuracy_order,
+                                    weno=True)
+    if equation.has_time_dependent_forcing:
+      model.set_forcing_from_equation(batch=1)
+    super(WENODifferentiator, self).__init__(model)
+    self.equation = equation
+
+
+def exact_differentiator(equation) -> Differentiator:
+  """The "exact" differentiator of an exact equation type (integrate.py:215-235)."""
+  if type(equation.to_exact()) is not type(equation):
+    raise TypeError('an exact equation must be provided')
+  method = equation.EXACT_METHOD
+  if method is equations_lib.ExactMethod.POLYNOMIAL:
+    return PolynomialDifferentiator(equation, accuracy_order=None)
+  if method is equations_lib.ExactMethod.SPECTRAL:
+    return SpectralDifferentiator(equation)
+  if method is equations_lib.ExactMethod.WENO:
+    return WENODifferentiator(equation)
+  raise TypeError('unexpected equation: {}'.format(equation))
+
+
 def odeint(y0: np.ndarray, differentiator: Differentiator, times: np.ndarray,
            method: str = 'RK23') -> Tuple[np.ndarray, int]:
   """integrate.py:143-169: SciPy solve_ivp, max_step 0.01, NaN-pad on failure."""
@@ -140,30 +201,100 @@ def odeint(y0: np.ndarray, differentiator: Differentiator, times: np.ndarray,
   return y, sol.nfev
 
 
+def odeint_with_periodic_filtering(y0: np.ndarray,
+                                   differentiator: Differentiator,
+                                   times: np.ndarray, filter_interval: float,
+                                   filter_order: int, method: str = 'RK23'):
+  """Integrate in segments, low-pass filtering between them (integrate.py:172-212).
+
+  Spectral methods for hyperbolic problems alias; every ``filter_interval`` the
+  state is passed through ``duckarray.smoothing_filter`` and the saved
+  trajectory is filtered once more at the end.
+  """
+  eps = 1e-8
+  split_times = np.arange(times[0], times[-1] + eps, filter_interval)
+  if not np.isin(split_times, times).all():
+    raise ValueError('all times in filter_interval must be sampled')
+  split_indexes = np.searchsorted(times, split_times, side='right')
+  pieces = [y0[np.newaxis, ...]]
+  num_evals = 0
+  for start, stop in zip(split_indexes[:-1], split_indexes[1:]):
+    segment, segment_evals = odeint(y0, differentiator, times[start - 1:stop],
+                                    method=method)
+    pieces.append(segment[1:])   # the first row repeats y0
+    y0 = duckarray.smoothing_filter(segment[-1], order=filter_order)
+    num_evals += segment_evals
+  y = np.concatenate(pieces, axis=0)
+  assert y.shape == (times.size, y0.size)
+  # filtering every saved step during integration would add noise; do it once
+  return duckarray.smoothing_filter(y, order=filter_order), num_evals
+
+
 def integrate(equation, differentiator: Differentiator,
               times: np.ndarray = _DEFAULT_TIMES, warmup: float = 0,
               integrate_method: str = 'RK23', filter_interval: float = None,
               filter_all_times: bool = False):
-  """integrate.py:238-279.
-
-  ``warmup`` / ``filter_interval`` need the fine-grid "exact" solvers (WENO /
-  spectral, integrate.py:108-140, 172-235), which are outside this path
-  (DESIGN.md "Out of scope"); they raise instead of silently differing.
-  """
-  if filter_interval is not None or filter_all_times:
-    raise NotImplementedError('periodic spectral filtering belongs to the '
-                              'exact solvers, outside the learned-stencil path')
+  """Integrate with optional exact warm-up and periodic filtering
+  (integrate.py:238-279)."""
+  if filter_interval is not None:
+    warmup_odeint = functools.partial(
+        odeint_with_periodic_filtering, filter_interval=filter_interval,
+        filter_order=max(equation.to_exact().DERIVATIVE_ORDERS))
+  else:
+    warmup_odeint = odeint
   if warmup:
-    raise NotImplementedError(
-        'warmup integrates the fine-grid exact equation (WENO / spectral); '
-        'provide y0 through integrate_model_from_warm_start instead')
-  y0 = equation.initial_value()
-  solution, num_evals = odeint(y0, differentiator, times=warmup + times,
-                               method=integrate_method)
+    equation_exact = equation.to_exact()
+    diff_exact = exact_differentiator(equation_exact)
+    if filter_interval is not None:
+      warmup_times = np.arange(0, warmup + 1e-8, filter_interval)
+    else:
+      warmup_times = np.array([0, warmup])
+    solution_warmup, _ = warmup_odeint(equation_exact.initial_value(),
+                                       diff_exact, times=warmup_times,
+                                       method=integrate_method)
+    # the state after warm-up, on this equation's grid, starts the run
+    y0 = equation.grid.resample(solution_warmup[-1, :])
+  else:
+    y0 = equation.initial_value()
+  odeint_func = warmup_odeint if filter_all_times else odeint
+  solution, num_evals = odeint_func(y0, differentiator, times=warmup + times,
+                                    method=integrate_method)
   return _make_dataset(
       data_vars={'y': (('time', 'x'), solution)},
       coords={'time': warmup + times, 'x': equation.grid.solution_x,
               'num_evals': num_evals})
+
+
+def integrate_exact(equation, times: np.ndarray = _DEFAULT_TIMES,
+                    warmup: float = 0, integrate_method: str = 'RK23',
+                    filter_interval: float = None):
+  """Integrate only the exact model (integrate.py:282-293)."""
+  equation = equation.to_exact()
+  return integrate(equation, exact_differentiator(equation), times, warmup,
+                   integrate_method=integrate_method,
+                   filter_interval=filter_interval)
+
+
+def integrate_weno(equation, times: np.ndarray = _DEFAULT_TIMES,
+                   warmup: float = 0, integrate_method: str = 'RK23',
+                   exact_filter_interval: float = None, **kwargs):
+  """integrate.py:311-325."""
+  if type(equation) not in equations_lib.FLUX_EQUATION_TYPES.values():
+    raise ValueError('invalid equation: {}'.format(equation))
+  return integrate(equation, WENODifferentiator(equation, **kwargs), times,
+                   warmup, integrate_method=integrate_method,
+                   filter_interval=exact_filter_interval)
+
+
+def integrate_spectral(equation, times: np.ndarray = _DEFAULT_TIMES,
+                       warmup: float = 0, integrate_method: str = 'RK23',
+                       exact_filter_interval: float = None):
+  """integrate.py:328-341."""
+  if type(equation) not in equations_lib.EQUATION_TYPES.values():
+    raise ValueError('invalid equation: {}'.format(equation))
+  return integrate(equation, SpectralDifferentiator(equation), times, warmup,
+                   integrate_method=integrate_method,
+                   filter_interval=exact_filter_interval)
 
 
 def integrate_baseline(equation, times: np.ndarray = _DEFAULT_TIMES,

@@ -26,6 +26,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _lib
+from . import duckarray
 from . import equations as equations_lib
 from . import hparams as hparams_lib
 from . import polynomials
@@ -525,31 +526,62 @@ class LearnedStencilModel(_DeviceModel):
 class BaselineModel(_DeviceModel):
   """Standard polynomial stencils (model.baseline_space_derivatives).
 
-  Reference: model.py:59-112 with an explicit ``accuracy_order``: per derivative
-  ``regular_grid(GRID_OFFSET, d, accuracy_order, dx)`` and
+  Reference: model.py:59-112.  With an explicit ``accuracy_order``: per
+  derivative ``regular_grid(GRID_OFFSET, d, accuracy_order, dx)`` and
   ``polynomials.coefficients`` (FV for conservative equations, FD otherwise).
-  ``accuracy_order=None`` selects the reference's "best polynomial" baseline
-  (6-point stencil, model.py:72-77) where EXACT_METHOD is POLYNOMIAL.
+  ``weno=True`` additionally replaces ``u_minus`` / ``u_plus`` of a
+  Godunov-flux equation by WENO5 reconstructions on the GPU, which is
+  ``integrate.WENODifferentiator`` (integrate.py:124-140).
+
+  ``accuracy_order=None`` selects the reference's best baseline
+  (model.py:69-95) for equations that are their own exact type: the 6-point
+  stencil for ExactMethod.POLYNOMIAL, WENO5 + third-order ``u_x`` for
+  ExactMethod.WENO (Godunov Burgers).  ExactMethod.SPECTRAL is
+  ``SpectralModel``.
   """
 
-  def __init__(self, equation, accuracy_order: Optional[int] = 1):
+  def __init__(self, equation, accuracy_order: Optional[int] = 1,
+               weno: bool = False):
     super(BaselineModel, self).__init__()
-    if accuracy_order is not None and type(equation) in (
-        equations_lib.FLUX_EQUATION_TYPES.values()):
-      raise AssertionError('explicit accuracy_order is not defined for '
-                           'numerical-flux equations (model.py:100)')
-    if accuracy_order is None:
-      raise NotImplementedError(
-          'best-baseline (WENO / spectral) space derivatives are outside the '
-          'learned-stencil path; see DESIGN.md "Out of scope"')
+    method = FINITE_VOL if equation.CONSERVATIVE else FINITE_DIFF
+    is_flux = type(equation) in equations_lib.FLUX_EQUATION_TYPES.values()
     self.equation = equation
     self.accuracy_order = accuracy_order
-    method = FINITE_VOL if equation.CONSERVATIVE else FINITE_DIFF
+    self.weno = bool(weno)
     self.stencils = []
-    for order in equation.DERIVATIVE_ORDERS:
-      grid = polynomials.regular_grid(equation.GRID_OFFSET, order,
-                                      accuracy_order, equation.grid.solution_dx)
-      self.stencils.append(polynomials.coefficients(grid, method, order))
+    if accuracy_order is None:
+      if equation.exact_type() is not type(equation):
+        raise AssertionError('the best baseline needs an exact equation type '
+                             '(model.py:70)')
+      exact = equation.EXACT_METHOD
+      if exact is equations_lib.ExactMethod.POLYNOMIAL:
+        for order in equation.DERIVATIVE_ORDERS:
+          grid = (0.5 + np.arange(-3, 3)) * equation.grid.solution_dx
+          self.stencils.append(polynomials.coefficients(grid, method, order))
+      elif exact is equations_lib.ExactMethod.WENO:
+        self.weno = True
+        for name, order in zip(equation.DERIVATIVE_NAMES,
+                               equation.DERIVATIVE_ORDERS):
+          if name in ('u_minus', 'u_plus'):
+            # placeholder rows: the kernel overwrites these two derivatives
+            self.stencils.append(np.zeros(2))
+            continue
+          if name != 'u_x':
+            raise AssertionError('best WENO baseline only knows u_x '
+                                 '(model.py:89)')
+          grid = polynomials.regular_grid(equation.GRID_OFFSET, order, 3,
+                                          equation.grid.solution_dx)
+          self.stencils.append(polynomials.coefficients(grid, method, order))
+      else:
+        raise ValueError('spectral best baseline: use SpectralModel')
+    else:
+      for order in equation.DERIVATIVE_ORDERS:
+        grid = polynomials.regular_grid(equation.GRID_OFFSET, order,
+                                        accuracy_order,
+                                        equation.grid.solution_dx)
+        self.stencils.append(polynomials.coefficients(grid, method, order))
+    if self.weno and not is_flux:
+      raise ValueError('WENO reconstruction needs a Godunov-flux equation')
     width = max(len(s) for s in self.stencils)
     # Centre every stencil in a common window so that tap i multiplies
     # u[x + i - width // 2] -- the alignment pad_periodic(center=True) gives
@@ -557,7 +589,7 @@ class BaselineModel(_DeviceModel):
     table = np.zeros((len(self.stencils), width), np.float32)
     for d, taps in enumerate(self.stencils):
       shift = width // 2 - len(taps) // 2
-      table[d, shift:shift + len(taps)] = taps.astype(np.float32)
+      table[d, shift:shift + len(taps)] = np.asarray(taps).astype(np.float32)
     self.stencil_size = width
     self.table = table
 
@@ -565,6 +597,7 @@ class BaselineModel(_DeviceModel):
     lib = _lib.load_library()
     _lib.require_gpu()
     cfg = self._base_config(self.equation, self.stencil_size)
+    cfg.weno_reconstruction = int(self.weno)
     handle = ctypes.c_void_p()
     flat = _lib.host_f32(self.table)
     _lib.check(lib.ddd_baseline_create(ctypes.byref(cfg), _lib.fptr(flat),
@@ -575,7 +608,115 @@ class BaselineModel(_DeviceModel):
     spec = dict(self.equation.kernel_spec())
     spec.update(resample_factor=self.equation.grid.resample_factor,
                 stencil_size=self.stencil_size,
-                baseline_coefficients=self.stencils)
+                baseline_coefficients=self.stencils, weno=self.weno)
+    return spec
+
+
+class SpectralModel(_DeviceModel):
+  """Spectral space derivatives + equation of motion in float64 on the GPU.
+
+  The fine-grid "exact" method of KdV and KS (ExactMethod.SPECTRAL):
+  ``integrate.SpectralDifferentiator`` (integrate.py:108-121, derivatives from
+  ``scipy.fftpack.diff``) and the spectral branch of
+  ``model.baseline_space_derivatives`` (model.py:78-80,
+  ``duckarray.spectral_derivative``).  Both are circulant linear operators;
+  their first columns are obtained by applying the reference's own call to a
+  unit impulse (``convention`` picks which), and the kernel evaluates
+  ``deriv[x] = sum_j c[(x - j) mod N] y[j]`` in float64.
+
+  No forcing on the device: ``finalize_time_derivative`` is applied by the
+  host-side differentiator in float64, as in the reference.
+  """
+
+  def __init__(self, equation, convention: str = 'fftpack'):
+    super(SpectralModel, self).__init__()
+    if type(equation) not in equations_lib.EQUATION_TYPES.values():
+      raise ValueError('invalid equation: {}'.format(equation))
+    if convention not in ('fftpack', 'rfft'):
+      raise ValueError('convention must be "fftpack" or "rfft"')
+    self.equation = equation
+    self.convention = convention
+    n = equation.grid.solution_num_points
+    period = equation.grid.period
+    impulse = np.zeros(n)
+    impulse[0] = 1.0
+    rows = []
+    for order in equation.DERIVATIVE_ORDERS:
+      if convention == 'fftpack':
+        import scipy.fftpack
+        rows.append(scipy.fftpack.diff(impulse, order, period))
+      else:
+        rows.append(duckarray.spectral_derivative(impulse, order, period))
+    self.kernels = np.ascontiguousarray(np.stack(rows), dtype=np.float64)
+    self.stencil_size = n
+
+  def _create_handle(self):
+    lib = _lib.load_library()
+    _lib.require_gpu()
+    cfg = self._base_config(self.equation, 1)
+    handle = ctypes.c_void_p()
+    _lib.check(lib.ddd_spectral_create(
+        ctypes.byref(cfg), self.kernels.ctypes.data_as(_lib._D),
+        self.kernels.size, ctypes.byref(handle)))
+    self._handle = handle
+
+  def set_forcing(self, forcing):
+    raise ValueError('spectral models carry no device forcing; '
+                     'finalize_time_derivative runs on the host')
+
+  def time_derivative(self, y, t: float = 0.0):
+    """equation_of_motion(y, spectral derivatives); y [batch, x] float64."""
+    lib = _lib.load_library()
+    torch, y = self._check_state(y, _lib._torch().float64)
+    out = torch.empty_like(y)
+    _lib.check(lib.ddd_time_derivative_f64(self._handle, float(t), y.data_ptr(),
+                                           out.data_ptr(), y.shape[0],
+                                           _lib.current_stream()))
+    return out
+
+  def space_derivatives(self, y):
+    raise NotImplementedError('spectral models expose time derivatives only')
+
+  coefficients = space_derivatives
+
+  def rk_substep(self, t, y_in, y_base=None, c1=1.0, y_out=None, acc_in=None,
+                 c2=0.0, acc_out=None):
+    lib = _lib.load_library()
+    torch, y_in = self._check_state(y_in, _lib._torch().float64)
+    ptr = lambda x: None if x is None else x.data_ptr()
+    _lib.check(lib.ddd_rk_substep_f64(
+        self._handle, float(t), y_in.data_ptr(), ptr(y_base), float(c1),
+        ptr(y_out), ptr(acc_in), float(c2), ptr(acc_out), y_in.shape[0],
+        _lib.current_stream()))
+
+  def integrate_fixed(self, y0, num_steps: int, dt: Optional[float] = None,
+                      t0: float = 0.0, scheme: str = 'midpoint',
+                      save_every: int = 1, launch_mode: str = 'per_substep',
+                      state_dtype: str = 'float64', out=None):
+    """Fixed-step explicit RK, state and right-hand side in float64."""
+    if self.equation.has_time_dependent_forcing:
+      raise ValueError('forced equations need the host finalize step: '
+                       'use integrate.SpectralDifferentiator with odeint')
+    if state_dtype != 'float64' or launch_mode != 'per_substep':
+      raise ValueError('spectral models step in float64, one launch per substep')
+    lib = _lib.load_library()
+    torch = _lib.require_gpu()
+    dt = self.equation.time_step if dt is None else dt
+    _, y0 = self._check_state(y0, torch.float64)
+    shape = (num_steps // save_every,) + tuple(y0.shape)
+    if out is None:
+      out = torch.empty(shape, dtype=torch.float64, device=y0.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float64 or not out.is_contiguous():
+      raise ValueError('out must be a contiguous float64 tensor of shape {}'.format(shape))
+    _lib.check(lib.ddd_integrate_fixed_f64(
+        self._handle, _lib.SCHEMES[scheme], float(t0), float(dt), int(num_steps),
+        int(save_every), y0.data_ptr(), out.data_ptr(), y0.shape[0],
+        _lib.current_stream()))
+    return out
+
+  def spec(self) -> dict:
+    spec = dict(self.equation.kernel_spec())
+    spec.update(spectral=True, convention=self.convention)
     return spec
 
 

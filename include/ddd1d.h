@@ -132,7 +132,12 @@ typedef struct ddd_config {
   int32_t polynomial_accuracy_order;    /* 0: net emits D*G coefficients */
   int32_t ensure_unbiased_coefficients; /* only with accuracy order 0 */
   int32_t input_sizes[DDD_MAX_DERIVATIVES]; /* null-space dims per derivative */
-  int32_t reserved[4];
+  int32_t weno_reconstruction; /* ddd_baseline_create only: 1 = derivative slots
+                                * 0 and 1 (u_minus, u_plus of the Godunov
+                                * equations) are WENO5 reconstructions
+                                * (weno.py:43-123, integrate.py:124-140,
+                                * model.py:82-88) instead of stencil rows */
+  int32_t reserved[3];
 } ddd_config;
 
 typedef struct ddd_model ddd_model;
@@ -167,6 +172,21 @@ int ddd_model_create(const ddd_config* cfg, const float* weights,
  * num_layers = 0 models (model.py:496-502) after folding on the host. */
 int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
                         size_t n_stencils, ddd_model** out);
+
+/* Replaces: integrate.SpectralDifferentiator.__init__ (integrate.py:110-111)
+ * and the ExactMethod.SPECTRAL branch of model.baseline_space_derivatives
+ * (model.py:78-80): the fine-grid "exact" solver of KdV / KS.  Float64.
+ * HOST `kernels` is [D][N] float64: for each derivative the response of the
+ * reference's spectral operator to a unit impulse at x = 0
+ * (scipy.fftpack.diff(delta, order, period) for SpectralDifferentiator,
+ * duckarray.spectral_derivative(delta, order, period) for the TF-graph form),
+ * so that deriv[x] = sum_j kernels[d][(x - j) mod N] * y[j].
+ * Non-flux equations only (DDD_EQ_BURGERS, DDD_EQ_KDV, DDD_EQ_KS:
+ * integrate.py:346-347), N <= 2048.  Only the *_f64 entry points below accept
+ * such a model; it carries no forcing (finalize_time_derivative stays on the
+ * host, where the reference evaluates it in float64). */
+int ddd_spectral_create(const ddd_config* cfg, const double* kernels,
+                        size_t n_kernels, ddd_model** out);
 
 int ddd_model_destroy(ddd_model* model);
 
@@ -224,6 +244,20 @@ int ddd_integrate_fixed(ddd_model* model, int scheme, int launch_mode,
 int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
                             int n_steps, int save_every, const double* y0,
                             double* y_out, int batch, void* stream);
+
+/* Float64 forms for spectral models (ddd_spectral_create).
+ * ddd_time_derivative_f64 replaces SpectralDifferentiator.__call__
+ * (integrate.py:113-121) without finalize_time_derivative, batched;
+ * ddd_rk_substep_f64 is ddd_rk_substep in float64:
+ *   f = equation_of_motion(y_in);  y_out = y_base + c1 f;  acc_out = acc_in + c2 f
+ * ddd_integrate_fixed_f64 on a spectral model steps with one fused launch per
+ * substep, state and right-hand side in float64. */
+int ddd_time_derivative_f64(ddd_model* model, double t, const double* y,
+                            double* dydt, int batch, void* stream);
+int ddd_rk_substep_f64(ddd_model* model, double t, const double* y_in,
+                       const double* y_base, double c1, double* y_out,
+                       const double* acc_in, double c2, double* acc_out,
+                       int batch, void* stream);
 
 /* ---- parity / debugging views of the same kernel ------------------------ */
 

@@ -13,7 +13,9 @@ Pinning status (see DESIGN.md "Oracle"):
     whose reference implementation is NumPy: stencil grids / constraints /
     coefficients / null-space layers, Grid + resampling, RandomForcing,
     equation_of_motion of all nine equations, staggered derivative, and the
-    SciPy RK23 driver ``integrate.odeint``.
+    SciPy RK23 driver ``integrate.odeint``; likewise (tests/golden/
+    make_golden_exact.py) the WENO5 reconstructions, the spectral derivative
+    and smoothing filter, SpectralDifferentiator and integrate_exact.
   * PINNED against the reference's own known-answer tables for periodic
     padding and convolution alignment (layers_test.py:49-86) and for stencil
     coefficients (polynomials_test.py:36-76, 116-157).
@@ -211,6 +213,106 @@ def baseline_space_derivatives(inputs, spec):
 
 
 # ---------------------------------------------------------------------------
+# weno.py -- in the dtype of ``u`` (float64 in the reference's NumPy callers,
+# float32 when checking the GPU kernel)
+# ---------------------------------------------------------------------------
+WENO_OPTIMAL_WEIGHTS = (0.1, 0.6, 0.3)
+
+
+def weno_smoothness_indicators(u):
+  """weno.py:43-58, Equation (7) of Tang (2005); returns [..., 3, x]."""
+  u = np.asarray(u)
+  f = u.dtype.type
+  m2, m1 = np.roll(u, 2, axis=-1), np.roll(u, 1, axis=-1)
+  p1, p2 = np.roll(u, -1, axis=-1), np.roll(u, -2, axis=-1)
+  q, r = f(1 / 4), f(13 / 12)
+  return np.stack([
+      q * (m2 - f(4) * m1 + f(3) * u) ** 2 + r * (m2 - f(2) * m1 + u) ** 2,
+      q * (m1 - p1) ** 2 + r * (m1 - f(2) * u + p1) ** 2,
+      q * (f(3) * u - f(4) * p1 + p2) ** 2 + r * (u - f(2) * p1 + p2) ** 2,
+  ], axis=-2)
+
+
+def weno_omega(u, weights=WENO_OPTIMAL_WEIGHTS, epsilon=1e-6, p=2):
+  """weno.py:61-75: alpha = w / (eps + IS)^p, omega = alpha / sum(alpha)."""
+  u = np.asarray(u)
+  f = u.dtype.type
+  indicator = weno_smoothness_indicators(u)
+  alpha = np.array(weights, dtype=u.dtype)[:, np.newaxis] / (f(epsilon) + indicator) ** p
+  return alpha / np.sum(alpha, axis=-2, keepdims=True)
+
+
+def weno_reconstruct_left(u):
+  """weno.py:78-101: u at the +1/2 edges from the left-biased stencil."""
+  u = np.asarray(u)
+  f = u.dtype.type
+  om = weno_omega(u)
+  o0, o1, o2 = om[..., 0, :], om[..., 1, :], om[..., 2, :]
+  coeff = [o0 / f(3), -(f(7) * o0 + o1) / f(6),
+           (f(11) * o0 + f(5) * o1 + f(2) * o2) / f(6),
+           (f(2) * o1 + f(5) * o2) / f(6), -o2 / f(6)]
+  total = 0
+  for c, shift in zip(coeff, (2, 1, 0, -1, -2)):
+    total = total + c * np.roll(u, shift, axis=-1)
+  return total
+
+
+def weno_reconstruct_right(u):
+  """weno.py:104-130 (weights reversed, omega rolled by -1)."""
+  u = np.asarray(u)
+  f = u.dtype.type
+  om = np.roll(weno_omega(u, WENO_OPTIMAL_WEIGHTS[::-1]), -1, axis=-1)
+  o2, o1, o0 = om[..., 0, :], om[..., 1, :], om[..., 2, :]
+  coeff = [-o2 / f(6), (f(5) * o2 + f(2) * o1) / f(6),
+           (f(2) * o2 + f(5) * o1 + f(11) * o0) / f(6),
+           -(o1 + f(7) * o0) / f(6), o0 / f(3)]
+  total = 0
+  for c, shift in zip(coeff, (1, 0, -1, -2, -3)):
+    total = total + c * np.roll(u, shift, axis=-1)
+  return total
+
+
+# ---------------------------------------------------------------------------
+# duckarray.py spectral helpers and integrate.SpectralDifferentiator (float64)
+# ---------------------------------------------------------------------------
+def spectral_derivative(x, order=1, period=2 * np.pi):
+  """duckarray.py:105-113 (rfft form; keeps the Nyquist mode for odd orders)."""
+  x = np.asarray(x)
+  length = x.shape[-1]
+  if length % 2:
+    raise ValueError('spectral derivative only works for even length data')
+  c = 2 * np.pi * 1j / period
+  k = np.fft.rfftfreq(length, d=1 / length)
+  return np.fft.irfft((c * k) ** order * np.fft.rfft(x))
+
+
+def smoothing_filter(x, alpha=-np.log(1e-15), order=2):
+  """duckarray.py:116-128 (Gottlieb & Hesthaven exponential filter)."""
+  x = np.asarray(x)
+  length = x.shape[-1]
+  if length % 2:
+    raise ValueError('smoothing filter only works for even length data')
+  count = length // 2
+  eta = np.arange(count + 1) / count
+  sigma = np.exp(-alpha * eta ** (2 * order))
+  return np.fft.irfft(sigma * np.fft.rfft(x))
+
+
+def spectral_time_derivative(equation, y, derivative_orders, period, eta, dx):
+  """integrate.SpectralDifferentiator.__call__ (integrate.py:113-121) without
+  finalize: scipy.fftpack.diff per derivative (third-party: SciPy, unpinned in
+  setup.py:25, called exactly as the reference calls it), then the equation
+  of motion, all float64."""
+  import scipy.fftpack
+  y = np.asarray(y, dtype=np.float64)
+  rows = y.reshape(-1, y.shape[-1])          # fftpack.diff is one-dimensional
+  derivs = np.stack([
+      np.stack([scipy.fftpack.diff(row, order, period) for row in rows]).reshape(y.shape)
+      for order in derivative_orders], axis=-1)
+  return equation_of_motion(equation, y, derivs, eta, dx)
+
+
+# ---------------------------------------------------------------------------
 # equations.py
 # ---------------------------------------------------------------------------
 def staggered_first_derivative(y, dx):
@@ -314,6 +416,11 @@ def time_derivative(spec, t, y, forcing=None):
   target = spec.get('model_target', 'coefficients')
   if spec.get('baseline_coefficients') is not None:
     derivs = baseline_space_derivatives(y32, spec)
+    if spec.get('weno'):
+      # integrate.py:134-138 / model.py:82-88: u_minus, u_plus replaced by the
+      # WENO reconstructions, rolled one cell to the left edge
+      derivs[..., 0] = np.roll(weno_reconstruct_left(y32), 1, axis=-1)
+      derivs[..., 1] = np.roll(weno_reconstruct_right(y32), 1, axis=-1)
     y_t = equation_of_motion(spec['equation'], y32, derivs, spec['eta'],
                              spec['dx'])
   elif target == 'time_derivative':          # model.py:603-606

@@ -155,5 +155,8 @@ def test_integrate_batch_argument_checks():
   with pytest.raises(ValueError, match='not a multiple'):
     integrate.integrate_batch(model, np.zeros((1, 64)), np.array([0, 0.015, 0.03]),
                               dt=0.01)
-  with pytest.raises(NotImplementedError, match='warmup'):
-    integrate.integrate(model.equation, integrate.Differentiator(), warmup=1.0)
+  # warm-up runs the fine-grid exact solver on the GPU: no silent CPU fallback
+  import torch
+  if not torch.cuda.is_available():
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+      integrate.integrate(model.equation, integrate.Differentiator(), warmup=1.0)

@@ -1,0 +1,189 @@
+"""Fine-grid "exact" solvers on the GPU: WENO5 + Godunov flux (float32 kernel,
+integrate.py:124-140) and the spectral method (float64 circulant kernel,
+integrate.py:108-121), against the oracle and against trajectories produced
+from the reference's own functions (tests/golden/make_golden_exact.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import oracle, baseline_spec, random_phase_ic, rel_err
+from ddd1d_amd import equations, integrate, model as model_lib
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TOL = 1e-5      # float32 kernels, as everywhere else
+TOL64 = 1e-9    # float64 spectral kernel vs the reference's FFT evaluation
+
+
+@pytest.fixture(scope='module')
+def exact():
+  return np.load(os.path.join(HERE, 'golden', 'reference_exact_solvers.npz'))
+
+
+@pytest.mark.parametrize('cls_name,n', [('GodunovBurgersEquation', 64),
+                                        ('GodunovBurgersEquation', 512),
+                                        ('GodunovKdVEquation', 64),
+                                        ('GodunovKSEquation', 96)])
+def test_weno_rhs_vs_oracle(cls_name, n):
+  eq = getattr(equations, cls_name)(n, random_seed=2)
+  model = model_lib.BaselineModel(eq, 3, weno=True)
+  spec = model.spec()
+  y = random_phase_ic(eq, 5)
+  y[1] = np.where(np.arange(n) < n // 2, 1.0, -0.5)     # a shock: nonlinear weights switch
+  got = model.time_derivative(y, 0.0).cpu().numpy()
+  want = oracle.time_derivative(spec, 0.0, y)
+  err = rel_err(got, want)
+  print(cls_name, n, 'rel err {:.2e}'.format(err))
+  assert err < (TOL if 'KS' not in cls_name else 1e-4)
+  derivs = model.space_derivatives(y).cpu().numpy()
+  np.testing.assert_allclose(derivs[..., 0], np.roll(oracle.weno_reconstruct_left(y), 1, axis=-1),
+                             rtol=0, atol=TOL * np.abs(y).max())
+  np.testing.assert_allclose(derivs[..., 1], np.roll(oracle.weno_reconstruct_right(y), 1, axis=-1),
+                             rtol=0, atol=TOL * np.abs(y).max())
+
+
+@pytest.mark.parametrize('cls_name,n,seed', [('GodunovBurgersEquation', 64, 3),
+                                             ('GodunovBurgersEquation', 128, 5),
+                                             ('GodunovKdVEquation', 64, 1)])
+def test_weno_differentiator_vs_reference_trajectories(exact, cls_name, n, seed):
+  """integrate_weno (SciPy RK23 + HIP WENO RHS, float32) against float64
+  trajectories assembled from reference functions."""
+  base = 'weno_odeint/%s/n%d/s%d' % (cls_name, n, seed)
+  eq = getattr(equations, cls_name)(n, random_seed=seed)
+  diff = integrate.WENODifferentiator(eq)
+  probe = exact[base + '/probe']
+  want_rhs = exact[base + '/rhs_t0.2_probe']
+  got_rhs = diff(0.2, probe)
+  assert rel_err(got_rhs, want_rhs) < 2e-5    # float32 kernel vs float64 reference
+  ds = integrate.integrate_weno(eq, times=exact[base + '/times'])
+  got = np.asarray(ds.data_vars['y'][1] if isinstance(ds.data_vars['y'], tuple)
+                   else ds['y'].data)
+  want = exact[base + '/y']
+  print(base, 'trajectory rel err {:.2e}'.format(rel_err(got, want)),
+        'nfev', int(np.asarray(ds.coords['num_evals'])), int(exact[base + '/nfev']))
+  assert rel_err(got, want) < 1e-4
+  # mean conservation of the flux form (integrate_test.py:101-104)
+  np.testing.assert_allclose(got.mean(axis=1), got[0].mean(), atol=1e-3)
+
+
+def test_best_weno_baseline_and_exact_differentiator():
+  eq = equations.GodunovBurgersEquation(128, random_seed=4)
+  best = model_lib.BaselineModel(eq, accuracy_order=None)
+  assert best.kernel_name == 'generic'
+  explicit = model_lib.BaselineModel(eq, 3, weno=True)
+  y = random_phase_ic(eq, 3)
+  np.testing.assert_array_equal(best.time_derivative(y, 0.0).cpu().numpy(),
+                                explicit.time_derivative(y, 0.0).cpu().numpy())
+  diff = integrate.exact_differentiator(eq)
+  assert isinstance(diff, integrate.WENODifferentiator)
+  assert isinstance(integrate.exact_differentiator(equations.KdVEquation(64)),
+                    integrate.SpectralDifferentiator)
+  with pytest.raises(TypeError, match='exact equation'):
+    integrate.exact_differentiator(equations.ConservativeBurgersEquation(64))
+
+
+@pytest.mark.parametrize('cls_name,n', [('KdVEquation', 64), ('KSEquation', 128),
+                                        ('BurgersEquation', 64)])
+def test_spectral_differentiator_vs_reference(exact, cls_name, n):
+  eq = getattr(equations, cls_name)(n, random_seed=3)
+  diff = integrate.SpectralDifferentiator(eq)
+  y = exact['spectral_rhs/%s/n%d/y' % (cls_name, n)]
+  want = exact['spectral_rhs/%s/n%d/out_t0.3' % (cls_name, n)]
+  got = diff(0.3, y)
+  assert got.dtype == np.float64
+  err = rel_err(got, want)
+  print(cls_name, n, 'spectral rhs rel err {:.2e}'.format(err))
+  assert err < TOL64
+
+
+def test_spectral_batched_and_rfft_convention():
+  eq = equations.KSEquation(256, random_seed=0)
+  y = random_phase_ic(eq, 33).astype(np.float64)
+  spec = eq.kernel_spec()
+  for convention in ('fftpack', 'rfft'):
+    model = model_lib.SpectralModel(eq, convention=convention)
+    got = model.time_derivative(y).cpu().numpy()
+    if convention == 'fftpack':
+      want = oracle.spectral_time_derivative(spec['equation'], y, spec['derivative_orders'],
+                                             spec['period'], spec['eta'], spec['dx'])
+    else:
+      derivs = np.stack([oracle.spectral_derivative(y, order, spec['period'])
+                         for order in spec['derivative_orders']], axis=-1)
+      want = oracle.equation_of_motion(spec['equation'], y, derivs, spec['eta'], spec['dx'])
+    assert rel_err(got, want) < TOL64
+  # float32 entry points refuse a spectral model, and vice versa
+  from ddd1d_amd import _lib
+  with pytest.raises(_lib.DDDError, match='f64'):
+    model_lib._DeviceModel.time_derivative(model, y.astype(np.float32))
+  base = model_lib.BaselineModel(equations.KdVEquation(64), 1)
+  with pytest.raises(_lib.DDDError, match='spectral model'):
+    model_lib.SpectralModel.time_derivative(base, random_phase_ic(base.equation, 2).astype(np.float64))
+
+
+def test_spectral_fixed_step_f64_vs_oracle():
+  """ddd_integrate_fixed_f64 on a spectral model: BS3 in float64 end to end."""
+  eq = equations.KdVEquation(64, random_seed=1)
+  model = model_lib.SpectralModel(eq)
+  spec = eq.kernel_spec()
+  y0 = random_phase_ic(eq, 4).astype(np.float64)
+  dt, steps = 1e-4, 50
+  got = model.integrate_fixed(y0, steps, dt=dt, scheme='bs3', save_every=25).cpu().numpy()
+  rhs = lambda y: oracle.spectral_time_derivative(
+      spec['equation'], y, spec['derivative_orders'], spec['period'], spec['eta'], spec['dx'])
+  y = y0.copy()
+  want = []
+  for step in range(steps):
+    k1 = rhs(y); k2 = rhs(y + 0.5 * dt * k1); k3 = rhs(y + 0.75 * dt * k2)
+    y = y + dt * (2 / 9 * k1 + 1 / 3 * k2 + 4 / 9 * k3)
+    if (step + 1) % 25 == 0:
+      want.append(y.copy())
+  assert got.dtype == np.float64
+  assert rel_err(got, np.stack(want)) < TOL64
+
+
+def test_integrate_exact_with_warmup_and_filtering(exact):
+  """integrate.integrate_exact end to end (warm-up on the exact equation,
+  periodic smoothing filter) against the reference's own runs."""
+  eq = equations.KdVEquation(64, random_seed=1)
+  ds = integrate.integrate_exact(eq, times=np.linspace(0, 0.1, 3), warmup=0.05)
+  got = _y(ds)
+  np.testing.assert_allclose(np.asarray(_coord(ds, 'time')), exact['exact/kdv64_warmup/times'])
+  assert rel_err(got, exact['exact/kdv64_warmup/y']) < 1e-6
+  eq = equations.KSEquation(64, random_seed=2)
+  ds = integrate.integrate_exact(eq, times=np.linspace(0, 0.04, 5), warmup=0.02,
+                                 filter_interval=0.01)
+  assert rel_err(_y(ds), exact['exact/ks64_filtered/y']) < 1e-6
+
+
+def test_integrate_with_warmup_for_a_coarse_baseline():
+  """integrate.integrate(warmup > 0): WENO warm-up on the fine Godunov grid,
+  resampled to the coarse conservative grid, then the coarse run
+  (integrate.py:256-268); t = warmup row equals the resampled warm-up state."""
+  fine, coarse = equations.from_hparams(_burgers_hparams(), random_seed=5)
+  ds = integrate.integrate_baseline(coarse, times=np.linspace(0, 0.1, 3), warmup=0.2)
+  y = _y(ds)
+  assert y.shape == (3, coarse.grid.solution_num_points) and np.isfinite(y).all()
+  exact_eq = coarse.to_exact()
+  warm, _ = integrate.odeint(exact_eq.initial_value(), integrate.exact_differentiator(exact_eq),
+                             np.array([0, 0.2]))
+  np.testing.assert_allclose(y[0], coarse.grid.resample(warm[-1]), rtol=0, atol=1e-6)
+  np.testing.assert_allclose(np.asarray(_coord(ds, 'time')), 0.2 + np.linspace(0, 0.1, 3))
+
+
+def _burgers_hparams():
+  import json
+  import ddd1d_amd
+  return ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=4,
+                                  equation_kwargs=json.dumps({'num_points': 128}))
+
+
+def _y(ds):
+  v = ds.data_vars['y']
+  return np.asarray(v[1] if isinstance(v, tuple) else v)
+
+
+def _coord(ds, name):
+  v = ds.coords[name]
+  return v[1] if isinstance(v, tuple) else v
