@@ -14,6 +14,8 @@ from . import layers
 from . import model
 from . import integrate
 from . import distributed
+from . import weno
+from . import evaluation
 from .hparams import HParams, create_hparams, load_hparams, save_hparams
 
 __version__ = '0.1.0'

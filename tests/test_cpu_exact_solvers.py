@@ -121,3 +121,46 @@ def test_best_baseline_model_tables():
     model_lib.BaselineModel(equations.ConservativeBurgersEquation(64), None)
   with pytest.raises(ValueError, match='invalid equation'):
     model_lib.SpectralModel(equations.ConservativeKdVEquation(64))
+
+
+# ---- known-answer tables of the reference's weno_test.py:30-96 -------------
+def test_weno_known_answers_smooth_weights():
+  u = np.zeros(5)
+  np.testing.assert_allclose(weno.calculate_omega(u), np.stack(5 * [[0.1, 0.6, 0.3]], axis=1))
+  np.testing.assert_allclose(weno.left_coefficients(u),
+                             np.stack(5 * [[2 / 60, -13 / 60, 47 / 60, 27 / 60, -3 / 60]]))
+  np.testing.assert_allclose(weno.right_coefficients(u),
+                             np.stack(5 * [[-3 / 60, 27 / 60, 47 / 60, -13 / 60, 2 / 60]]))
+
+
+def test_weno_known_answers_discontinuity():
+  u = np.array([0, 1, 2, 3, 4, -4, -3, -2, -1])
+  for mod in (weno, ):
+    np.testing.assert_allclose(mod.reconstruct_left(u),
+                               [0.5, 1.5, 2.5, 3.5, 4.5, -3.5, -2.5, -1.5, -0.5], atol=0.005)
+    np.testing.assert_allclose(mod.reconstruct_right(u),
+                               [0.5, 1.5, 2.5, 3.5, -4.5, -3.5, -2.5, -1.5, -0.5], atol=0.005)
+  uf = u.astype(np.float64)
+  np.testing.assert_allclose(oracle.weno_reconstruct_left(uf), weno.reconstruct_left(uf), atol=1e-13)
+  np.testing.assert_allclose(oracle.weno_reconstruct_right(uf), weno.reconstruct_right(uf), atol=1e-13)
+
+
+@pytest.mark.parametrize('u', [
+    [0, 0, 0, 0, 1, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 0, 0, 0, 0, 0],
+    [1, 2, 3, 4, 5, 0, 0, 0, 0, 0], [0, 0, 1, 2, 3, 0, 0, 0, 0, 0],
+    [0, 0, 0, 1, 2, 0, 0, 0, 0, 0], list(2 * np.random.RandomState(0).rand(10))])
+def test_weno_reflection_symmetry(u):
+  u = np.array(u, dtype=float)
+  flip_staggered = lambda x: np.roll(x, +1)[::-1]
+  np.testing.assert_allclose(weno.reconstruct_left(u),
+                             flip_staggered(weno.reconstruct_right(u[::-1])), atol=1e-6)
+  np.testing.assert_allclose(weno.reconstruct_right(u),
+                             flip_staggered(weno.reconstruct_left(u[::-1])), atol=1e-6)
+
+
+def test_weno_batched():
+  ub = np.array([[0, 0, 0, 1, 2, 3, 4], [0, 0, 1, 2, 3, 4, 5]], dtype=float)
+  np.testing.assert_allclose(weno.reconstruct_left(ub),
+                             np.stack([weno.reconstruct_left(r) for r in ub]))
+  np.testing.assert_allclose(weno.reconstruct_right(ub),
+                             np.stack([weno.reconstruct_right(r) for r in ub]))
