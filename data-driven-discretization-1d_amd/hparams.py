@@ -188,8 +188,20 @@ def save_hparams(hparams: HParams, checkpoint_dir: str) -> str:
 
 
 def load_hparams(checkpoint_dir: str) -> HParams:
-  """Load hparams saved next to a model checkpoint (training.py:639-647)."""
+  """Load hparams saved next to a model checkpoint (training.py:639-647).
+
+  Reads this package's ``hparams.json`` or, when only the reference's
+  ``hparams.pbtxt`` (text-format HParamDef, training.py:590-592) is present,
+  that; values missing from the file take the defaults, as in the reference.
+  """
   path = os.path.join(checkpoint_dir, HPARAMS_FILENAME)
+  if not os.path.exists(path):
+    from . import checkpoint
+    pbtxt = os.path.join(checkpoint_dir, checkpoint.HPARAMS_PBTXT)
+    if os.path.exists(pbtxt):
+      with open(pbtxt) as f:
+        values = checkpoint.parse_hparams_pbtxt(f.read())
+      return create_hparams(**values)
   with open(path) as f:
     text = f.read()
   equation = json.loads(text)['equation']

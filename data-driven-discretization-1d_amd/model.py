@@ -489,6 +489,16 @@ class LearnedStencilModel(_DeviceModel):
       hparams = hparams_lib.load_hparams(checkpoint_dir)
     if equation is None:
       _, equation = equations_lib.from_hparams(hparams, random_seed=random_seed)
+    from . import checkpoint
+    if (not os.path.exists(os.path.join(checkpoint_dir, WEIGHTS_FILENAME)) and
+        checkpoint.has_tf_checkpoint(checkpoint_dir)):
+      # the reference's own artefact: hparams.pbtxt + model.ckpt.  Only the conv
+      # tower is stored; the null-space tables are rebuilt from the hparams
+      # exactly as model.predict_coefficients does at restore time
+      # (model.py:480-489) -- and, as there, depend on the local LAPACK's SVD.
+      kernels, conv_biases = checkpoint.load_conv_weights(checkpoint_dir,
+                                                          hparams.num_layers)
+      return cls(equation, hparams, kernels, conv_biases)
     with np.load(os.path.join(checkpoint_dir, WEIGHTS_FILENAME)) as data:
       kernels = [data['conv{}_kernel'.format(i)]
                  for i in range(hparams.num_layers)]
