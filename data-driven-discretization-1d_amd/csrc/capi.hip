@@ -377,6 +377,25 @@ int check_batch(const ddd_model* m, int batch, bool want_spectral = false) {
 // rows on four wavefronts with block barriers.
 struct MfmaGeometry { int rows, wave_rows; };
 
+// One-time hardware check of the DPP wavefront rotate the one-wave kernel uses
+// for the flux exchange when N = 64 (falls back to ds_bpermute otherwise).
+int dpp_wave_rol_ok() {
+  static int ok = -1;
+  if (ok >= 0) return ok;
+  ok = 0;
+  float* d = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&d), 64 * sizeof(float)) != hipSuccess) return ok;
+  hipLaunchKernelGGL(ddd::ops::dpp_rotate_probe_kernel, dim3(1), dim3(64), 0, nullptr, d);
+  float h[64];
+  if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+    ok = 1;
+    for (int l = 0; l < 64; ++l)
+      if (h[l] != (float)(((l + 1) % 64) * 3 + 1)) ok = 0;
+  }
+  (void)hipFree(d);
+  return ok;
+}
+
 int device_simds() {
   static int simds = 0;
   if (simds == 0) {
@@ -431,6 +450,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   }
   m->last_substep_kernel = m->kernel == DDD_KERNEL_MFMA ? "mfma" : "generic";
   if (m->kernel == DDD_KERNEL_MFMA) {
+    m->dp.dpp_rol = dpp_wave_rol_ok();
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     const int spg = geo.rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
@@ -474,6 +494,7 @@ int spec_equation(const ddd_model* m) {
 
 template <int kRows, int kWR, typename ST>
 void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
+  m->dp.dpp_rol = dpp_wave_rol_ok();
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
@@ -1212,7 +1233,12 @@ int ddd_selftest_mfma_layout(void) {
                     "mfma_f32_16x16x4 layout mismatch at D[%d][%d]: got %g want %g", i, j,
                     h16[i * 16 + j], want);
     }
+  // informational: the kernels fall back to ds_bpermute when this is 0
+  (void)dpp_wave_rol_ok();
   return DDD_OK;
 }
+
+// 1 if the DPP wavefront rotate is usable on this device (tests / diagnostics).
+int ddd_debug_dpp_wave_rol(void) { return dpp_wave_rol_ok(); }
 
 }  // extern "C"

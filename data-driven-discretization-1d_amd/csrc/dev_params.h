@@ -31,6 +31,7 @@ struct DevParams {
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
   int weno;            // fixed only: derivatives 0 / 1 are WENO5 reconstructions
+  int dpp_rol;         // 1: `v_mov_b32_dpp wave_rol:1` verified on this device (capi.hip)
   int target, L, F, K, act, C_out, pao, unbiased;
   int in_start[kMaxDerivs], in_size[kMaxDerivs], ns_off[kMaxDerivs];
   int w_off[kMaxLayers], b_off[kMaxLayers], cin[kMaxLayers], cout[kMaxLayers];

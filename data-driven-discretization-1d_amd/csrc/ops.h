@@ -81,6 +81,17 @@ __global__ void polynomial_accuracy_kernel(const float* __restrict__ in,
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// DPP wavefront rotate: out[l] = in[(l + 1) % 64] if `wave_rol:1` does what the
+// flux exchange of the one-wave kernel assumes.
+__device__ __forceinline__ float wave_rotate_left1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /* wave_rol:1 */,
+                                                    0xf, 0xf, false));
+}
+
+__global__ void dpp_rotate_probe_kernel(float* __restrict__ out) {
+  out[threadIdx.x] = wave_rotate_left1((float)(threadIdx.x * 3 + 1));
+}
+
 __global__ void mfma_layout_probe_kernel(float* __restrict__ out32,
                                          float* __restrict__ out16) {
   const int l = threadIdx.x;

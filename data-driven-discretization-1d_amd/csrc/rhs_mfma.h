@@ -676,8 +676,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     if (kOneWave) {
       // whole samples live in this wavefront: the right neighbour's flux comes
       // straight from its lane
-      fnext = __shfl(r, pow2 ? (((ln.pos + 1) & (p.N - 1)) | ln.base)
-                                  : wrap_row(ln.base, ln.pos, 1, p.N), 64);
+      if (p.N == 64 && p.dpp_rol)   // one sample = one wavefront: a DPP rotate
+        fnext = ops::wave_rotate_left1(r);
+      else
+        fnext = __shfl(r, pow2 ? (((ln.pos + 1) & (p.N - 1)) | ln.base)
+                                    : wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
       if (ln.owner) sm.flux[ln.row] = r;
       __syncthreads();
