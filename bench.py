@@ -199,6 +199,8 @@ def main():
     achieved_tflops = flops_per_launch / launch_s / 1e12
     achieved_gbps = bytes_per_launch / launch_s / 1e9
     compute_bound = not args.baseline_stencils
+    traffic = measured_traffic(type(eq).__name__, n, batch, args.launch_mode,
+                               args.baseline_stencils)
     result = {
         'metric': 'grid-point-steps/s',
         'value': total_points / wall,
@@ -232,7 +234,7 @@ def main():
             'unit': 'TFLOP/s' if compute_bound else 'GB/s',
             'frac': (achieved_tflops / PEAK_FP32_TFLOPS if compute_bound
                      else achieved_gbps / PEAK_HBM_GBPS),
-            'traffic': None,
+            'traffic': traffic,
             'kernel_ms_per_launch': kernel_ms / launches,
             'launches': launches,
             'hbm_gbps': achieved_gbps,
@@ -249,6 +251,26 @@ def main():
     print(json.dumps(result))
   if world > 1:
     dist.destroy_process_group()
+
+
+def measured_traffic(equation, num_points, batch, launch_mode, fixed):
+  """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+  PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction
+  applied; profiles/r1_hbm_traffic.json), or None when this configuration was
+  not profiled.  bench.py cannot collect counters itself."""
+  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                      'r1_hbm_traffic.json')
+  try:
+    with open(path) as f:
+      table = json.load(f)
+  except (OSError, ValueError):
+    return None
+  want = dict(equation=equation, num_points=num_points, batch_per_gpu=batch,
+              launch_mode=launch_mode, fixed=bool(fixed))
+  for entry in table.get('entries', []):
+    if entry.get('match') == want:
+      return entry['traffic_bytes_per_launch']
+  return None
 
 
 if __name__ == '__main__':

@@ -136,6 +136,7 @@ struct ddd_model {
   int kernel = DDD_KERNEL_GENERIC;   // resolved family
   int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
+  bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
   const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
@@ -445,9 +446,11 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
     hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel, dim3(blocks),
                        dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
     m->last_substep_kernel = "stream_fixed";
+    m->last_launch_streamed = true;
     DDD_HIP(hipGetLastError());
     return DDD_OK;
   }
+  m->last_launch_streamed = false;
   m->last_substep_kernel = m->kernel == DDD_KERNEL_MFMA ? "mfma" : "generic";
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
@@ -529,6 +532,7 @@ template <typename ST>
 int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
   m->last_batch = a.batch;
+  m->last_launch_streamed = false;
   {
     // profiling knobs (see profiles/r1_ablation.txt); all off by default
     const char* env = std::getenv("DDD_PRIO_SPLIT");
@@ -1149,6 +1153,8 @@ int ddd_set_kernel(ddd_model* m, int kind) {
 
 const char* ddd_kernel_name(const ddd_model* m) {
   if (m == nullptr) return "";
+  if (m->spectral) return "spectral_f64";
+  if (m->last_launch_streamed) return "stream_fixed";
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";

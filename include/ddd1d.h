@@ -294,9 +294,10 @@ int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
 
 /* ---- introspection -------------------------------------------------------*/
 int ddd_set_kernel(ddd_model* model, int kernel_kind);
-/* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256" or "generic": the kernel
- * family and workgroup geometry of the most recent launch on this handle (the
- * automatic choice depends on the batch size). */
+/* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256", "generic",
+ * "stream_fixed" (fixed stencils, one launch per substep) or "spectral_f64":
+ * the kernel family and workgroup geometry of the most recent launch on this
+ * handle (the automatic choice depends on the batch size and launch mode). */
 const char* ddd_kernel_name(const ddd_model* model);
 /* Algorithmic multiply-adds per grid point per right-hand-side evaluation
  * (SURVEY.md section 8(d)); 2x this is the FLOP count used for the roofline. */
