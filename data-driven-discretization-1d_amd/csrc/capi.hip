@@ -150,6 +150,7 @@ struct ddd_model {
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
   float* d_trig = nullptr;
+  unsigned char* d_runs = nullptr;
   // spectral (float64) models: ddd_spectral_create
   bool spectral = false;
   ddd::spectral::Params sp{};
@@ -422,6 +423,22 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   return {64, 64};
 }
 
+// Equation id of the compile-time specialised integrator this model can use,
+// or -1: the default architecture (three relu conv layers, default stencil
+// width, projection folded when D <= 2) on a non-Godunov equation.
+int spec_equation(const ddd_model* m) {
+  const ddd::DevParams& dp = m->dp;
+  const char* off = std::getenv("DDD_NO_SPEC");
+  if (off != nullptr && off[0] == '1') return -1;
+  if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
+  if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
+  if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
+  if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
+  if ((dp.conservative != 0) != ddd::mfma::spec_flux_form(dp.equation)) return -1;
+  if ((dp.folded != 0) != (dp.D <= 2)) return -1;
+  return dp.equation;
+}
+
 bool aligned16(const void* ptr) {
   return (reinterpret_cast<uintptr_t>(ptr) & 15u) == 0;
 }
@@ -457,15 +474,37 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     const int spg = geo.rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
-    if (geo.rows == 64 && geo.wave_rows == 64)
-      hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64>), dim3(blocks), dim3(64), 0,
-                         stream, m->dp, a);
-    else if (geo.rows == 64)
-      hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 32>), dim3(blocks), dim3(128), 0,
-                         stream, m->dp, a);
-    else
-      hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64>), dim3(blocks), dim3(256), 0,
-                         stream, m->dp, a);
+    // per-equation instantiations for the plain substep (no derivative views)
+    const int eq = (a.derivs_out == nullptr && a.coeffs_out == nullptr && geo.wave_rows == 64)
+                       ? spec_equation(m) : -1;
+#define DDD_SUBSTEP_CASE(EQ)                                                                \
+    case EQ:                                                                               \
+      if (geo.rows == 64)                                                                  \
+        hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64, EQ>), dim3(blocks), dim3(64), \
+                           0, stream, m->dp, a);                                           \
+      else                                                                                 \
+        hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64, EQ>), dim3(blocks),         \
+                           dim3(256), 0, stream, m->dp, a);                                \
+      break;
+    switch (eq) {
+      DDD_SUBSTEP_CASE(ddd::EQ_BURGERS)
+      DDD_SUBSTEP_CASE(ddd::EQ_BURGERS_CONS)
+      DDD_SUBSTEP_CASE(ddd::EQ_KDV)
+      DDD_SUBSTEP_CASE(ddd::EQ_KDV_CONS)
+      DDD_SUBSTEP_CASE(ddd::EQ_KS)
+      DDD_SUBSTEP_CASE(ddd::EQ_KS_CONS)
+      default:
+        if (geo.rows == 64 && geo.wave_rows == 64)
+          hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64>), dim3(blocks), dim3(64), 0,
+                             stream, m->dp, a);
+        else if (geo.rows == 64)
+          hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 32>), dim3(blocks), dim3(128), 0,
+                             stream, m->dp, a);
+        else
+          hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64>), dim3(blocks), dim3(256), 0,
+                             stream, m->dp, a);
+    }
+#undef DDD_SUBSTEP_CASE
   } else {
     int rc = check_generic_lds(m, 0);
     if (rc) return rc;
@@ -477,22 +516,6 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   }
   DDD_HIP(hipGetLastError());
   return DDD_OK;
-}
-
-// Equation id of the compile-time specialised integrator this model can use,
-// or -1: the default architecture (three relu conv layers, default stencil
-// width, projection folded when D <= 2) on a non-Godunov equation.
-int spec_equation(const ddd_model* m) {
-  const ddd::DevParams& dp = m->dp;
-  const char* off = std::getenv("DDD_NO_SPEC");
-  if (off != nullptr && off[0] == '1') return -1;
-  if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
-  if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
-  if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
-  if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
-  if ((dp.conservative != 0) != ddd::mfma::spec_flux_form(dp.equation)) return -1;
-  if ((dp.folded != 0) != (dp.D <= 2)) return -1;
-  return dp.equation;
 }
 
 template <int kRows, int kWR, typename ST>
@@ -822,6 +845,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
   free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
   if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
@@ -832,8 +856,9 @@ int ddd_model_destroy(ddd_model* m) {
 int ddd_clear_forcing(ddd_model* m) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
   free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
-  m->d_frc = nullptr; m->d_sp = nullptr; m->d_trig = nullptr;
-  m->dp.trig = nullptr;
+  if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
+  m->d_frc = nullptr; m->d_sp = nullptr; m->d_trig = nullptr; m->d_runs = nullptr;
+  m->dp.trig = nullptr; m->dp.runs = nullptr;
   m->dp.forced = 0; m->dp.P = 0; m->dp.n_k = 0; m->dp.forcing_batch = 0;
   m->dp.frc = nullptr; m->dp.sp = nullptr;
   return DDD_OK;
@@ -886,10 +911,33 @@ int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude
       trig[(size_t)x * 12 + 2 * k + 0] = (float)std::cos(theta);
       trig[(size_t)x * 12 + 2 * k + 1] = (float)std::sin(theta);
     }
+  // runs[b][kk] = first (sorted) mode of sample b whose k index is >= kk: the
+  // kernels' per-(sample, k) sums cover modes [runs[kk], runs[kk + 1])
+  std::vector<unsigned char> runs((size_t)batch * 8, 0);
+  if (nparams < 256)
+    for (int b = 0; b < batch; ++b) {
+      int mode = 0;
+      for (int kk = 0; kk < 8; ++kk) {
+        while (mode < nparams) {
+          int32_t ki;
+          std::memcpy(&ki, &packed[(size_t)b * nparams + mode].w, sizeof(ki));
+          if (ki >= kk) break;
+          ++mode;
+        }
+        runs[(size_t)b * 8 + kk] = (unsigned char)mode;
+      }
+    }
   rc = upload(packed, &m->d_frc);
   if (!rc) rc = upload(sp, &m->d_sp);
   if (!rc) rc = upload(trig, &m->d_trig);
+  if (!rc) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->d_runs), runs.size());
+    if (e == hipSuccess)
+      e = hipMemcpy(m->d_runs, runs.data(), runs.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(DDD_ERR_HIP, "forcing runs upload: %s", hipGetErrorString(e));
+  }
   if (rc) return rc;
+  m->dp.runs = m->d_runs;
   m->dp.trig = m->d_trig;
   m->dp.frc = m->d_frc;
   m->dp.sp = m->d_sp;

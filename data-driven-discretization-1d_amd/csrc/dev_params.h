@@ -59,6 +59,7 @@ struct DevParams {
   const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)
   const float* sp;         // [n_k][N]   spatial phase table
   const float* trig;       // [N][12] cos / sin of the spatial phases, zero padded
+  const unsigned char* runs;   // [batch][8]: first mode of each sample with k index >= kk
 };
 
 // Explicit RK tableau in "previous-stage only" form:

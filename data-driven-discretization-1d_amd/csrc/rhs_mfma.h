@@ -61,7 +61,6 @@ struct Shared {
   float flux[kRows == kWR ? 1 : kRows];  // one-wave groups exchange flux by shuffle
   float2 pm[kPmMax];              // per (sample, mode): a sin(psi), a cos(psi)
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
-  unsigned char ks[kRows];        // per sample: start of each k's run of modes, [8]
   float tab[kTabRows * kGMax];    // [0,4): bias8[d][8]; [4,20): ns8 rows per channel
 };
 static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
@@ -752,25 +751,15 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
       res.frc_a = q.x; res.frc_omega = q.y; res.frc_phi = q.z;
     }
   }
-  if (fast) {
-    // ks[sl][kk] = first mode of sample sl whose k index is >= kk (modes sorted)
-    if (tid < spg) {
-      const long sample = (long)blockIdx.x * spg + tid;
-      int m = 0;
-      for (int kk = 0; kk < 8; ++kk) {
-        if (sample < batch)
-          while (m < p.P && __float_as_int(p.frc[sample * p.P + m].w) < kk) ++m;
-        sm.ks[tid * 8 + kk] = (unsigned char)m;
-      }
-    }
-  }
+  // this lane's run of modes [m0, m1): runs[sample][kk] = first (sorted) mode of
+  // the sample whose k index is >= kk, precomputed by ddd_set_forcing
   res.frc_run = 0;
-  if (fast) {
-    __syncthreads();   // sm.ks visible
-    if (tid < spg * p.n_k * 2) {
-      const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
-      const int kk = (tid >> 1) - sl * p.n_k;
-      const int m0 = sm.ks[sl * 8 + kk], m1 = sm.ks[sl * 8 + kk + 1];
+  if (fast && tid < spg * p.n_k * 2) {
+    const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
+    const int kk = (tid >> 1) - sl * p.n_k;
+    const long sample = (long)blockIdx.x * spg + sl;
+    if (sample < batch) {
+      const int m0 = p.runs[sample * 8 + kk], m1 = p.runs[sample * 8 + kk + 1];
       res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
                     ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
     }
@@ -782,7 +771,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
 // Kernel 1: one fused RK substep (also: plain time derivative, derivative and
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
-template <int kRows, int kWR>
+template <int kRows, int kWR, int kEq = -1>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams p,
                                                                       SubstepArgs a) {
   __shared__ Shared<kRows, kWR> sm;
@@ -791,7 +780,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
-  const float f = eval_rhs<kRows, kWR, false, -1>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
+  const float f = eval_rhs<kRows, kWR, false, kEq>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
                                               fast_frc, a.derivs_out, a.coeffs_out, 64);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
