@@ -121,7 +121,7 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid
   const int spg = kRows / p.N;
   ln.rows_used = spg * p.N;
   ln.inv_n = 1.0f / (float)p.N;
-  if ((p.N & (p.N - 1)) == 0) {   // wave-uniform
+  if (kRows == 64 || (p.N & (p.N - 1)) == 0) {   // N | 64 is a power of two; else wave-uniform
     ln.pos = ln.row & (p.N - 1);
     ln.base = ln.row - ln.pos;
     ln.sl = ln.row >> (31 - __builtin_clz(p.N));
@@ -161,9 +161,10 @@ __device__ __forceinline__ int tile_src_row(const Lane& ln, int trow, int off, i
 // Rows of grid points (pos - 2 .. pos + 2) mod N for tile row `trow`: the five
 // conv taps.  One sample lookup per tile row, then one compare/select per tap
 // (the sign of each offset is known at compile time).
+template <bool kPow2>
 __device__ __forceinline__ void tap_rows(const Lane& ln, int trow, int n,
                                          int (&rows)[kKW]) {
-  if ((n & (n - 1)) == 0) {
+  if (kPow2 || (n & (n - 1)) == 0) {
     // N a power of two (divides the group's rows, no spare rows): samples
     // start at multiples of N, so the wrap is an AND and the base an OR:
     // one v_add + one v_and_or per tap.  (wave-uniform branch)
@@ -488,7 +489,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const bool folded = kSpec ? (spec_derivs(kEq) <= 2) : (p.folded != 0);
   const int act = kSpec ? (int)ACT_RELU : p.act;
   const int nL = kHoist ? 3 : p.L;
-  const bool pow2 = (p.N & (p.N - 1)) == 0;   // wave-uniform
+  const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
   const int tid = opaque((int)threadIdx.x);
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid);
@@ -500,10 +501,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (!fixed) {
 #pragma unroll
     for (int t2 = 0; t2 < kWR / 32; ++t2)
-      tap_rows(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
+      tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
 #pragma unroll
     for (int t2 = 0; t2 < kWR / 16; ++t2)
-      tap_rows(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
+      tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
   }
   const float un_reg = u / p.stddev;   // model.py:450-451, a true division
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
@@ -658,7 +659,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       }
       float s = 0.0f;
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) s = fmaf(cf[d][g], pch[g], s);
+      for (int g = 0; g < kGMax; ++g)
+        if (!kSpec || g < nG) s = fmaf(cf[d][g], pch[g], s);   // padded columns: cf = 0
       dv[d] = s;
     }
   }
