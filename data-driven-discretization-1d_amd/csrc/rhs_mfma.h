@@ -813,8 +813,10 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
   // one of them win every arbitration, which de-synchronises the pair so one
   // wave's VALU / LDS phases overlap the other's MFMA phases
   // (MI355X_MICROARCH.md "Two waves per SIMD", item 4).
-  int ablate = a.ablate & 0xff;
-  if ((a.ablate >> 8) != 0 &&
+  // DDD_ABLATE (profiling) is honoured by the run-time-parameterised
+  // instantiation only (DDD_NO_SPEC=1 selects it for the default models)
+  int ablate = kEq >= 0 ? 0 : (a.ablate & 0xff);
+  if (kEq < 0 && (a.ablate >> 8) != 0 &&
       ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) != 0))
     ablate = (a.ablate >> 8) & 0xff;   // DDD_ABLATE high byte: mask for odd wave slots
   if (a.prio_split) {   // A/B experiments (DDD_PRIO_SPLIT / DDD_STAGGER), off by default
