@@ -532,7 +532,19 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
       hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true, EQ>), grid, \
                          block, 0, stream, m->dp, a);                                  \
       return;
-    switch (spec_equation(m)) {
+    int eq = spec_equation(m);
+    if (a.trace != nullptr) {
+      // phase tracing: the dedicated traced instantiation (headline config) or
+      // the run-time-parameterised kernel
+      if (eq == ddd::EQ_BURGERS_CONS && kRows == 64) {
+        hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true,
+                                                        ddd::EQ_BURGERS_CONS, true>),
+                           grid, block, 0, stream, m->dp, a);
+        return;
+      }
+      eq = -1;
+    }
+    switch (eq) {
       DDD_SPEC_CASE(ddd::EQ_BURGERS)
       DDD_SPEC_CASE(ddd::EQ_BURGERS_CONS)
       DDD_SPEC_CASE(ddd::EQ_KDV)

@@ -471,13 +471,13 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
-template <int kRows, int kWR, bool kHoist, int kEq>
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
                                           unsigned long long* trace = nullptr) {
-#define DDD_STAMP(i) do { if (trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
   constexpr bool kSpec = kEq >= 0;
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
-  const float f = eval_rhs<kRows, kWR, false, kEq>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
+  const float f = eval_rhs<kRows, kWR, false, kEq, false>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
                                               fast_frc, a.derivs_out, a.coeffs_out, 64);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
@@ -800,7 +800,10 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1>
+// kTrace: s_memtime phase stamps (DDD_TRACE_PTR, profiles/tools/trace_phases.py)
+// are compiled into the run-time-parameterised instantiation and into one
+// dedicated specialised instantiation only: their branches cost ~2 % otherwise.
+template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0)>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
                                                                         IntegrateArgs a) {
   __shared__ Shared<kRows, kWR> sm;
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
       unsigned long long* tr = nullptr;
-      if (a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
+      if (kTrace && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
         tr = a.trace + (size_t)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       const double tn = s + 1 < a.tab.stages
                             ? t + a.tab.c[s + 1] * a.dt
                             : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
-      const float f = eval_rhs<kRows, kWR, kHoist, kEq>(p, sm, a.batch, (float)us,
+      const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(p, sm, a.batch, (float)us,
                                               (float)(t + a.tab.c[s] * a.dt), (float)tn, res,
                                               fast_frc, nullptr, nullptr, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
