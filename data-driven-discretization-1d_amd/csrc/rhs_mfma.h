@@ -286,19 +286,24 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  const float4* rowp[kT][kKW];
+  // 32-bit float offsets (not pointers: pointer arrays make the compiler carry
+  // 64-bit address arithmetic for what ends up as an LDS offset)
+  int rowo[kT][kKW];
 #pragma unroll
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowp[t][tap] = reinterpret_cast<const float4*>(in + rows[t][tap] * kHS + 16 * half);
+      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)kHS) + 16 * half;   // rows < 256
+  const auto operand = [&](int t, int tap, int q) {
+    return *reinterpret_cast<const float4*>(in + rowo[t][tap] + 4 * q);
+  };
   f32x16 acc[kT];
   float4 cur[kT], nxt[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    cur[t] = rowp[t][0][0];
+    cur[t] = operand(t, 0, 0);
   }
   __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
 #pragma unroll
@@ -306,7 +311,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
       nxt[t] = cur[t];
-      if (g + 1 < 20) nxt[t] = rowp[t][(g + 1) >> 2][(g + 1) & 3];
+      if (g + 1 < 20) nxt[t] = operand(t, (g + 1) >> 2, (g + 1) & 3);
     }
 #pragma unroll
     for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[4 * g + 0], cur[t].x, acc[t]);
@@ -361,25 +366,28 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
   // accumulators are independent chains issued round-robin (a dependent
   // 16x16x4 needs 40 cycles, the pipe takes one every 32), and the reads of
   // group g + 1 are issued before the MFMAs of group g.
-  const float4* rowp[kT][kKW];
+  int rowo[kT][kKW];   // 32-bit float offsets, see hidden_layer
 #pragma unroll
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowp[t][tap] = reinterpret_cast<const float4*>(in + rows[t][tap] * kHS + 8 * quarter);
+      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)kHS) + 8 * quarter;
+  const auto operand = [&](int t, int tap, int q) {
+    return *reinterpret_cast<const float4*>(in + rowo[t][tap] + 4 * q);
+  };
   f32x4 acc[kT];
   float4 cur[kT], nxt[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    cur[t] = rowp[t][0][0];
+    cur[t] = operand(t, 0, 0);
   }
   __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
 #pragma unroll
   for (int g = 0; g < 10; ++g) {
     if (g + 1 < 10) {
 #pragma unroll
-      for (int t = 0; t < kT; ++t) nxt[t] = rowp[t][(g + 1) >> 1][(g + 1) & 1];
+      for (int t = 0; t < kT; ++t) nxt[t] = operand(t, (g + 1) >> 1, (g + 1) & 1);
     }
     const float* w = wf + 4 * g;
 #pragma unroll
