@@ -16,6 +16,7 @@ from . import integrate
 from . import distributed
 from . import weno
 from . import evaluation
-from .hparams import HParams, create_hparams, load_hparams, save_hparams
+from .hparams import (HParams, create_hparams, load_hparams, save_hparams,
+                      checkpoint_dir_to_path)
 
 __version__ = '0.1.0'

@@ -206,3 +206,9 @@ def load_hparams(checkpoint_dir: str) -> HParams:
     text = f.read()
   equation = json.loads(text)['equation']
   return create_hparams(equation).parse_json(text)
+
+
+def checkpoint_dir_to_path(checkpoint_dir: str) -> str:
+  """Prefix of the reference's TF checkpoint files (training.py:523-524)."""
+  return os.path.join(checkpoint_dir, 'model.ckpt')
+

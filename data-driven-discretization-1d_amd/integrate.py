@@ -113,16 +113,45 @@ class SavedModelDifferentiator(_HipDifferentiator):
 
 
 class PolynomialDifferentiator(_HipDifferentiator):
-  """Standard finite difference / volume stencils (integrate.py:74-105)."""
+  """Standard finite difference / volume stencils (integrate.py:74-105).
+
+  ``accuracy_order=None`` is the reference's "best baseline"
+  (model.py:69-95): the 6-point stencil, WENO5, or -- for the equations whose
+  exact method is spectral -- ``duckarray.spectral_derivative``, which here
+  runs on the float64 circulant kernel (``model.SpectralModel('rfft')``; the
+  reference evaluates that branch in a float32 TF graph).
+  """
 
   def __init__(self, equation, accuracy_order: Optional[int] = 1):
+    self.equation = equation
+    self._spectral = (
+        accuracy_order is None and
+        equation.EXACT_METHOD is equations_lib.ExactMethod.SPECTRAL)
+    if self._spectral:
+      if equation.exact_type() is not type(equation):
+        raise AssertionError('the best baseline needs an exact equation type '
+                             '(model.py:70)')
+      self.model = model_lib.SpectralModel(equation, convention='rfft')
+      self._torch = _lib.require_gpu()
+      return
     model = model_lib.BaselineModel(equation, accuracy_order)
     if equation.has_time_dependent_forcing:
       model.set_forcing_from_equation(batch=1)
     super(PolynomialDifferentiator, self).__init__(model)
-    self.equation = equation
+
+  def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
+    if not self._spectral:
+      return super(PolynomialDifferentiator, self).__call__(t, y)
+    y64 = np.ascontiguousarray(np.asarray(y, dtype=np.float64)[np.newaxis, :])
+    y_t = self.model.time_derivative(y64, t)[0].cpu().numpy()
+    return self.equation.finalize_time_derivative(t, y_t)
 
   def calculate_space_derivatives(self, y):
+    if self._spectral:
+      return {name: duckarray.spectral_derivative(np.asarray(y, np.float64), order,
+                                                  self.equation.grid.period)
+              for name, order in zip(self.equation.DERIVATIVE_NAMES,
+                                     self.equation.DERIVATIVE_ORDERS)}
     y32 = np.ascontiguousarray(np.asarray(y, dtype=np.float32)[np.newaxis, :])
     derivs = self.model.space_derivatives(y32)[0].cpu().numpy()
     return {name: derivs[:, i]

@@ -187,3 +187,20 @@ def _y(ds):
 def _coord(ds, name):
   v = ds.coords[name]
   return v[1] if isinstance(v, tuple) else v
+
+
+def test_best_baseline_for_spectral_equations():
+  """PolynomialDifferentiator(accuracy_order=None) on a spectral-exact equation:
+  duckarray.spectral_derivative (rfft form, model.py:78-80) through the
+  float64 kernel."""
+  eq = equations.KdVEquation(64, random_seed=6)
+  diff = integrate.PolynomialDifferentiator(eq, accuracy_order=None)
+  y = random_phase_ic(eq, 1)[0].astype(np.float64)
+  spec = eq.kernel_spec()
+  derivs = np.stack([oracle.spectral_derivative(y, order, spec['period'])
+                     for order in spec['derivative_orders']], axis=-1)
+  want = oracle.equation_of_motion(spec['equation'], y, derivs, spec['eta'], spec['dx'])
+  assert rel_err(diff(0.0, y), want) < TOL64
+  named = diff.calculate_space_derivatives(y)
+  assert sorted(named) == sorted(eq.DERIVATIVE_NAMES)
+  np.testing.assert_allclose(named['u_x'], derivs[..., 0], rtol=0, atol=1e-12)
