@@ -47,6 +47,12 @@ P('(integrate_kernel<64,64,float,true,1,false> = the ConservativeBurgers special
 P(' warm-up launch [MinNs] + the timed 1000-step launch [MaxNs]; bench.py HIP-event time of the timed launch in a')
 P(' separate un-profiled run: %.3f ms -> %.2f TFLOP/s fp32 = %.1f %% of 157.3)\n' % (
     d['roofline']['kernel_ms_per_launch'], d['roofline']['achieved'], 100 * d['roofline']['frac']))
+if os.path.exists(O + '/prof_default_w1000/bench_kernel_stats.csv'):
+  stats('default_w1000', 'python bench.py --warmup 1000 --cpu-seconds 0   (warm-up launch as long as the timed one)')
+  dd = json.loads([l for l in open(O + '/prof_default_w1000.log') if l.startswith('{')][0])
+  P('(the first launch of the process is cold -- code object load, clocks ramping -- and runs ~1.7x slower; the second,')
+  P(' timed launch [MinNs] is the steady state and agrees with bench.py\'s HIP-event time in the same run: %.3f ms)\n' % (
+      dd['roofline']['kernel_ms_per_launch']))
 stats('stream', 'python bench.py --equation kdv --baseline-stencils --launch-mode per_substep '
                 '--batch 262144 --steps 100 --warmup 10 --cpu-seconds 0')
 d = json.load(open(O + '/bench_fixed_kdv_persub.json'))
