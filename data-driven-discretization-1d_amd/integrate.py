@@ -13,6 +13,7 @@ Mirror of ``pde_superresolution/integrate.py`` for the learned-stencil path:
   integrate                      integrate.py:238-279 (warm-up + filtering)
   integrate_exact / _weno / _spectral  integrate.py:282-341
   integrate_baseline             integrate.py:296-308
+  integrate_exact_baseline_and_model integrate.py:344-396
   integrate_model_from_warm_start integrate.py:399-427
 
 plus ``integrate_batch``: the whole batch of independent initial conditions
@@ -335,6 +336,65 @@ def integrate_baseline(equation, times: np.ndarray = _DEFAULT_TIMES,
   return integrate(equation, differentiator, times, warmup,
                    integrate_method=integrate_method,
                    filter_interval=exact_filter_interval)
+
+
+def integrate_exact_baseline_and_model(checkpoint_dir: Optional[str],
+                                       hparams=None, random_seed: int = 0,
+                                       times: np.ndarray = _DEFAULT_TIMES,
+                                       warmup: float = 0,
+                                       integrate_method: str = 'RK23',
+                                       exact_filter_interval: float = None,
+                                       model=None):
+  """Exact (fine grid), baseline and learned-model solutions of one sample
+  (integrate.py:344-396): the fine equation through its exact solver, then --
+  from the exact solution's first row resampled to the coarse grid -- standard
+  finite differences and the neural-network stencils."""
+  if hparams is None:
+    hparams = (model.hparams if model is not None
+               else hparams_lib.load_hparams(checkpoint_dir))
+  logging.info('integrating %s with seed=%s', hparams.equation, random_seed)
+  equation_fine, equation_coarse = equations_lib.from_hparams(
+      hparams, random_seed=random_seed)
+  logging.info('solving the "exact" model at high resolution')
+  ds_exact = integrate_exact(equation_fine, times, warmup,
+                             integrate_method=integrate_method,
+                             filter_interval=exact_filter_interval)
+  solution_exact = _dataset_array(ds_exact, 'y')
+  num_evals_exact = int(np.asarray(_dataset_coord(ds_exact, 'num_evals')))
+  y0 = equation_coarse.grid.resample(solution_exact[0, :])
+  if np.isnan(y0).any():
+    raise ValueError('solution contains NaNs')
+  logging.info('solving baseline finite differences at low resolution')
+  solution_baseline, num_evals_baseline = odeint(
+      y0, PolynomialDifferentiator(equation_coarse), warmup + times,
+      method=integrate_method)
+  logging.info('solving neural network model at low resolution')
+  differentiator = SavedModelDifferentiator(checkpoint_dir, equation_coarse,
+                                            hparams, model=model)
+  solution_model, num_evals_model = odeint(y0, differentiator, warmup + times,
+                                           method=integrate_method)
+  return _make_dataset(
+      data_vars={'y_exact': (('time', 'x_high'), solution_exact),
+                 'y_baseline': (('time', 'x_low'), solution_baseline),
+                 'y_model': (('time', 'x_low'), solution_model)},
+      coords={'time': warmup + times,
+              'x_low': equation_coarse.grid.solution_x,
+              'x_high': equation_fine.to_exact().grid.solution_x,
+              'num_evals_exact': num_evals_exact,
+              'num_evals_baseline': num_evals_baseline,
+              'num_evals_model': num_evals_model})
+
+
+def _dataset_array(ds, name):
+  value = ds.data_vars[name] if not _HAVE_XARRAY else ds[name].data
+  return np.asarray(value[1] if isinstance(value, tuple) else value)
+
+
+def _dataset_coord(ds, name):
+  value = ds.coords[name]
+  if _HAVE_XARRAY:
+    return value.values
+  return value[1] if isinstance(value, tuple) else value
 
 
 def integrate_model_from_warm_start(checkpoint_dir: Optional[str],

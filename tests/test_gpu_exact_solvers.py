@@ -204,3 +204,28 @@ def test_best_baseline_for_spectral_equations():
   named = diff.calculate_space_derivatives(y)
   assert sorted(named) == sorted(eq.DERIVATIVE_NAMES)
   np.testing.assert_allclose(named['u_x'], derivs[..., 0], rtol=0, atol=1e-12)
+
+
+def test_integrate_exact_baseline_and_model():
+  """integrate.py:344-396 end to end: WENO exact solution on the fine grid,
+  then baseline and learned model from its resampled first row."""
+  from helpers import make_model
+  model = make_model('burgers', True, num_points=32, resample_factor=4)
+  times = np.linspace(0, 0.2, 3)
+  ds = integrate.integrate_exact_baseline_and_model(None, hparams=model.hparams,
+                                                    random_seed=3, times=times,
+                                                    warmup=0.1, model=model)
+  exact = _y_named(ds, 'y_exact'); base = _y_named(ds, 'y_baseline'); learned = _y_named(ds, 'y_model')
+  assert exact.shape == (3, 128) and base.shape == (3, 32) and learned.shape == (3, 32)
+  assert np.isfinite(exact).all() and np.isfinite(base).all() and np.isfinite(learned).all()
+  # both coarse runs start from the block-averaged exact state
+  np.testing.assert_allclose(base[0], exact[0].reshape(32, 4).mean(axis=1), atol=1e-12)
+  np.testing.assert_array_equal(base[0], learned[0])
+  # the baseline tracks the resampled exact solution closely over this horizon
+  assert np.abs(base[-1] - exact[-1].reshape(32, 4).mean(axis=1)).max() < 0.05
+  np.testing.assert_allclose(np.asarray(_coord(ds, 'time')), 0.1 + times)
+
+
+def _y_named(ds, name):
+  v = ds.data_vars[name]
+  return np.asarray(v[1] if isinstance(v, tuple) else v)
