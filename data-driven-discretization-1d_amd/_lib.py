@@ -108,6 +108,15 @@ SIGNATURES = {
     'ddd_pad_periodic': (ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, ctypes.c_int,
                                         ctypes.c_int, _V]),
+    'ddd_extract_patches': (ctypes.c_int, [_V, _V, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, _V]),
+    'ddd_apply_coefficients': (ctypes.c_int, [_V, _V, _V, ctypes.c_int,
+                                              ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int, _V]),
+    'ddd_apply_space_derivatives': (ctypes.c_int, [ctypes.c_int, _V, _V, _V,
+                                                   ctypes.c_int, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_double,
+                                                   ctypes.c_double, _V]),
     'ddd_polynomial_accuracy_apply': (ctypes.c_int, [_V, _V, _V, _V,
                                                      ctypes.c_int64,
                                                      ctypes.c_int,
@@ -247,6 +256,47 @@ def polynomial_accuracy_apply(inputs, nullspace, bias):
   check(lib.ddd_polynomial_accuracy_apply(
       x.data_ptr(), ns.data_ptr(), b.data_ptr(), out.data_ptr(), rows,
       input_size, g, current_stream()))
+  return out
+
+
+def extract_patches(inputs, size: int):
+  """model.extract_patches on the GPU: [batch, x] -> [batch, x, size]."""
+  lib = load_library()
+  torch = require_gpu()
+  x = as_device(inputs, torch.float32)
+  if x.dim() != 2:
+    raise ValueError('inputs must be [batch, x]')
+  out = torch.empty(tuple(x.shape) + (int(size),), dtype=torch.float32, device=x.device)
+  check(lib.ddd_extract_patches(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1],
+                                int(size), current_stream()))
+  return out
+
+
+def apply_coefficients(coefficients, inputs):
+  """model.apply_coefficients on the GPU: einsum('bxdi,bxi->bxd') with patches."""
+  lib = load_library()
+  torch = require_gpu()
+  c = as_device(coefficients, torch.float32)
+  x = as_device(inputs, torch.float32)
+  if c.dim() != 4 or x.dim() != 2 or tuple(c.shape[:2]) != tuple(x.shape):
+    raise ValueError('expected coefficients [batch, x, derivative, stencil] and inputs [batch, x]')
+  out = torch.empty(tuple(c.shape[:3]), dtype=torch.float32, device=x.device)
+  check(lib.ddd_apply_coefficients(c.data_ptr(), x.data_ptr(), out.data_ptr(), x.shape[0],
+                                   x.shape[1], c.shape[2], c.shape[3], current_stream()))
+  return out
+
+
+def apply_space_derivatives(equation_id: int, derivatives, inputs, eta: float, dx: float):
+  lib = load_library()
+  torch = require_gpu()
+  d = as_device(derivatives, torch.float32)
+  x = as_device(inputs, torch.float32)
+  if d.dim() != 3 or x.dim() != 2 or tuple(d.shape[:2]) != tuple(x.shape):
+    raise ValueError('expected derivatives [batch, x, derivative] and inputs [batch, x]')
+  out = torch.empty_like(x)
+  check(lib.ddd_apply_space_derivatives(int(equation_id), d.data_ptr(), x.data_ptr(),
+                                        out.data_ptr(), x.shape[0], x.shape[1], d.shape[2],
+                                        float(eta), float(dx), current_stream()))
   return out
 
 

@@ -1159,6 +1159,52 @@ int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c, int p
   return DDD_OK;
 }
 
+int ddd_extract_patches(const float* in, float* out, int batch, int n, int size, void* stream) {
+  if (!in || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (batch < 0 || n < 1 || size < 1) return fail(DDD_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (batch == 0) return DDD_OK;
+  const long total = (long)batch * n * size;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 65535);
+  hipLaunchKernelGGL(ddd::ops::extract_patches_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, batch, n, size);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_apply_coefficients(const float* coefficients, const float* in, float* out, int batch,
+                           int n, int d, int g, void* stream) {
+  if (!coefficients || !in || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (batch < 0 || n < 1 || d < 1 || g < 1) return fail(DDD_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (batch == 0) return DDD_OK;
+  const long total = (long)batch * n * d;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 65535);
+  hipLaunchKernelGGL(ddd::ops::apply_coefficients_kernel, dim3(blocks), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), coefficients, in, out, batch, n, d, g);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_apply_space_derivatives(int equation, const float* derivatives, const float* y,
+                                float* out, int batch, int n, int d, double eta, double dx,
+                                void* stream) {
+  if (!derivatives || !y || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (equation < DDD_EQ_BURGERS || equation > DDD_EQ_KS_GODUNOV)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown equation %d", equation);
+  if (batch < 0 || n < 2 || d < 1 || d > DDD_MAX_DERIVATIVES || !(dx > 0))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "bad sizes");
+  if (batch == 0) return DDD_OK;
+  const bool flux_form = equation == DDD_EQ_BURGERS_CONSERVATIVE ||
+                         equation == DDD_EQ_KDV_CONSERVATIVE ||
+                         equation == DDD_EQ_KS_CONSERVATIVE || equation >= DDD_EQ_BURGERS_GODUNOV;
+  const size_t lds = (size_t)n * sizeof(float);
+  if (lds > 64 * 1024) return fail(DDD_ERR_UNSUPPORTED, "num_points too large");
+  hipLaunchKernelGGL(ddd::ops::apply_space_derivatives_kernel, dim3(batch), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), derivatives, y, out, equation, n, d,
+                     (float)eta, (float)(1.0 / dx), flux_form ? 1 : 0);
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
 int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
                                   const float* bias, float* out, int64_t m,
                                   int input_size, int g, void* stream) {

@@ -81,6 +81,69 @@ __global__ void polynomial_accuracy_kernel(const float* __restrict__ in,
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// model.extract_patches (model.py:516-533): out[b][x][i] = in[b][(x + i - size/2) mod N]
+// -- pad_periodic(size - 1, center=True) + tf.extract_image_patches.
+__global__ void extract_patches_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                       int batch, int n, int size) {
+  const long total = (long)batch * n * size;
+  const int left = size / 2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int i = (int)(idx % size);
+    const long bx = idx / size;
+    const int x = (int)(bx % n);
+    const long b = bx / n;
+    int src = (x + i - left) % n;
+    src = src < 0 ? src + n : src;
+    out[idx] = in[b * n + src];
+  }
+}
+
+// model.apply_coefficients (model.py:536-548):
+// out[b][x][d] = sum_i coeff[b][x][d][i] * in[b][(x + i - G/2) mod N]   (einsum 'bxdi,bxi->bxd')
+__global__ void apply_coefficients_kernel(const float* __restrict__ coeff,
+                                          const float* __restrict__ in,
+                                          float* __restrict__ out, int batch, int n, int d,
+                                          int g) {
+  const long total = (long)batch * n * d;
+  const int left = g / 2;
+  for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long bx = idx / d;
+    const int x = (int)(bx % n);
+    const long b = bx / n;
+    const float* __restrict__ c = coeff + idx * g;
+    float acc = 0.0f;
+    for (int i = 0; i < g; ++i) {
+      int src = (x + i - left) % n;
+      src = src < 0 ? src + n : src;
+      acc = fmaf(c[i], in[b * n + src], acc);
+    }
+    out[idx] = acc;
+  }
+}
+
+// model.apply_space_derivatives (model.py:115-135): equation_of_motion on given
+// derivatives; flux forms take the staggered difference of the flux
+// (equations.py:305-320).  One workgroup per sample, flux staged in LDS.
+__global__ void apply_space_derivatives_kernel(const float* __restrict__ derivs,
+                                               const float* __restrict__ y,
+                                               float* __restrict__ out, int equation, int n,
+                                               int d, float eta, float inv_dx, int flux_form) {
+  extern __shared__ float flux[];
+  const size_t off = (size_t)blockIdx.x * n;
+  for (int x = threadIdx.x; x < n; x += blockDim.x) {
+    float dv[kMaxDerivs] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int j = 0; j < d && j < kMaxDerivs; ++j) dv[j] = derivs[(off + x) * d + j];
+    flux[x] = equation_rhs_or_flux(equation, y[off + x], dv, eta);
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < n; x += blockDim.x) {
+    const float here = flux[x];
+    out[off + x] = flux_form ? -(inv_dx * (flux[x + 1 == n ? 0 : x + 1] - here)) : here;
+  }
+}
+
 // DPP wavefront rotate: out[l] = in[(l + 1) % 64] if `wave_rol:1` does what the
 // flux exchange of the one-wave kernel assumes.
 __device__ __forceinline__ float wave_rotate_left1(float v) {

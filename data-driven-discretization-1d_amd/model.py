@@ -733,6 +733,32 @@ class SpectralModel(_DeviceModel):
 # ---------------------------------------------------------------------------
 # functional API with the reference's names
 # ---------------------------------------------------------------------------
+def assert_consistent_solution(equation, solution):
+  """model.py:42-56: the last axis must match the equation's grid."""
+  if equation.grid.solution_num_points != np.shape(solution)[-1]:
+    raise ValueError('solution has unexpected size for equation: {} vs {}'.format(
+        np.shape(solution)[-1], equation.grid.solution_num_points))
+
+
+def extract_patches(inputs, size: int):
+  """model.py:516-533: [batch, x] -> [batch, x, size] periodic patches."""
+  return _lib.extract_patches(inputs, size)
+
+
+def apply_coefficients(coefficients, inputs):
+  """model.py:536-548: combine stencil coefficients with patches of ``inputs``."""
+  return _lib.apply_coefficients(coefficients, inputs)
+
+
+def apply_space_derivatives(derivatives, inputs, equation):
+  """model.py:115-135: the equation of motion on given space derivatives
+  [batch, x, derivative] (DERIVATIVE_NAMES order); no finalize step."""
+  assert_consistent_solution(equation, inputs)
+  spec = equation.kernel_spec()
+  return _lib.apply_space_derivatives(spec['equation'], derivatives, inputs,
+                                      spec['eta'], spec['dx'])
+
+
 def predict_coefficients(inputs, model: LearnedStencilModel):
   return model.coefficients(inputs)
 

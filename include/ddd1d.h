@@ -286,6 +286,24 @@ int ddd_conv1d_periodic(const float* in, const float* filters,
 int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c,
                      int padding, int center, void* stream);
 
+/* Replaces: model.extract_patches (model.py:516-533).
+ * in [batch][N] -> out [batch][N][size], out[b][x][i] = in[b][(x + i - size/2) mod N]. */
+int ddd_extract_patches(const float* in, float* out, int batch, int n, int size,
+                        void* stream);
+
+/* Replaces: model.apply_coefficients (model.py:536-548).
+ * coefficients [batch][N][D][G], in [batch][N] -> out [batch][N][D]. */
+int ddd_apply_coefficients(const float* coefficients, const float* in, float* out,
+                           int batch, int n, int d, int g, void* stream);
+
+/* Replaces: model.apply_space_derivatives (model.py:115-135):
+ * Equation.equation_of_motion on given derivatives [batch][N][D] (order of
+ * DERIVATIVE_NAMES) and the state y [batch][N] -> time derivative [batch][N],
+ * without finalize_time_derivative.  `equation` is a ddd_equation. */
+int ddd_apply_space_derivatives(int equation, const float* derivatives, const float* y,
+                                float* out, int batch, int n, int d, double eta,
+                                double dx, void* stream);
+
 /* Replaces: PolynomialAccuracyLayer.apply (polynomials.py:266-277).
  * inputs [m][input_size], nullspace [input_size][G], bias [G], out [m][G]. */
 int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,

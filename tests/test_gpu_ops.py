@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import oracle, rel_err
-from ddd1d_amd import layers, polynomials, _lib
+from ddd1d_amd import equations, layers, polynomials, _lib, model as model_lib
 
 pytestmark = pytest.mark.gpu
 
@@ -116,3 +116,49 @@ def test_reconstruct_matches_oracle():
 
 def test_mfma_layout_selftest():
   _lib.selftest_mfma_layout()
+
+
+def test_extract_patches_alignment_and_apply_coefficients():
+  """model.extract_patches / apply_coefficients (model.py:516-548): patch i of
+  point x is u[x + i - size // 2]; for even sizes the quantity sits at the left
+  cell edge (offsets -3..+2 for size 6)."""
+  u = np.arange(8, dtype=np.float32)[None, :] * 10
+  got6 = model_lib.extract_patches(u, 6).cpu().numpy()
+  np.testing.assert_array_equal(got6[0, 0], [50, 60, 70, 0, 10, 20])
+  np.testing.assert_array_equal(got6[0, 4], [10, 20, 30, 40, 50, 60])
+  got7 = model_lib.extract_patches(u, 7).cpu().numpy()
+  np.testing.assert_array_equal(got7[0, 0], [50, 60, 70, 0, 10, 20, 30])
+  rs = np.random.RandomState(0)
+  y = rs.randn(5, 48).astype(np.float32)
+  for size in (3, 6, 7):
+    np.testing.assert_array_equal(model_lib.extract_patches(y, size).cpu().numpy(),
+                                  oracle.extract_patches(y, size))
+    coeff = rs.randn(5, 48, 3, size).astype(np.float32)
+    got = model_lib.apply_coefficients(coeff, y).cpu().numpy()
+    want = oracle.apply_coefficients(coeff, y)
+    assert rel_err(got, want) < 1e-6
+  with pytest.raises(ValueError):
+    model_lib.apply_coefficients(np.zeros((2, 8, 2, 6), np.float32), np.zeros((2, 9), np.float32))
+
+
+@pytest.mark.parametrize('cls', [
+    equations.BurgersEquation, equations.ConservativeBurgersEquation,
+    equations.GodunovBurgersEquation, equations.KdVEquation,
+    equations.ConservativeKdVEquation, equations.GodunovKdVEquation,
+    equations.KSEquation, equations.ConservativeKSEquation, equations.GodunovKSEquation])
+def test_apply_space_derivatives_all_equations(cls):
+  """model.apply_space_derivatives (model.py:115-135) for all nine equations."""
+  eq = cls(64, random_seed=0)
+  rs = np.random.RandomState(1)
+  y = rs.randn(3, 64).astype(np.float32)
+  derivs = rs.randn(3, 64, len(eq.DERIVATIVE_NAMES)).astype(np.float32)
+  got = model_lib.apply_space_derivatives(derivs, y, eq).cpu().numpy()
+  spec = eq.kernel_spec()
+  want = oracle.equation_of_motion(spec['equation'], y, derivs, spec['eta'], spec['dx'])
+  assert rel_err(got, want) < 1e-6
+  # and the host mirror of the reference's own method (bit-identical to it)
+  named = {n: derivs[..., i].astype(np.float64) for i, n in enumerate(eq.DERIVATIVE_NAMES)}
+  ref = eq.equation_of_motion(y.astype(np.float64), named)
+  assert rel_err(got, ref) < 1e-5
+  with pytest.raises(ValueError, match='unexpected size'):
+    model_lib.apply_space_derivatives(derivs, y[:, :32], eq)
