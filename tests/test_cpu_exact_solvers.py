@@ -164,3 +164,18 @@ def test_weno_batched():
                              np.stack([weno.reconstruct_left(r) for r in ub]))
   np.testing.assert_allclose(weno.reconstruct_right(ub),
                              np.stack([weno.reconstruct_right(r) for r in ub]))
+
+
+@pytest.mark.parametrize('y,period', [
+    (np.sin(2 * np.pi * np.arange(8) / 8), 1), (np.sin(2 * np.pi * np.arange(8) / 8), 8),
+    (np.linspace(-1, 1, num=12) ** 2, 2)])
+def test_spectral_derivative_vs_fftpack(y, period):
+  """The reference's duckarray_test.py:56-66: orders 0-2 agree with
+  scipy.fftpack.diff (they differ only in the Nyquist mode of odd orders)."""
+  import scipy.fftpack
+  for order in range(3):
+    expected = scipy.fftpack.diff(y, order=order, period=period)
+    np.testing.assert_allclose(duckarray.spectral_derivative(y, order, period), expected,
+                               atol=1e-12)
+    np.testing.assert_allclose(oracle.spectral_derivative(y, order, period), expected,
+                               atol=1e-12)
