@@ -109,6 +109,22 @@ def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
     steps += chunk
     chunk = min(chunk * 2, 4096)
   points = sample * ys.shape[1] * steps
+  # reference-style execution shape: ONE sample,
+  # SciPy RK23 (max_step 0.01) driving the NumPy restatement of the RHS, one
+  # core -- how the reference itself runs (integrate.py:143-169)
+  one_forcing = {k: v[0] for k, v in forcing.items()}
+  t_end = 0.25
+  t0 = time.perf_counter()
+  _, nfev = oracle.odeint_rk23(model.spec(), y0[0], np.array([0.0, t_end]), one_forcing)
+  ref_elapsed = time.perf_counter() - t0
+  ref_steps = max((nfev - 2) // 3, 1)          # RK23: 3 evaluations per step (FSAL)
+  reference_style = {
+      'value': ys.shape[1] * ref_steps / ref_elapsed, 'unit': 'grid-point-steps/s',
+      'cores': 1,
+      'sample': 'one sample, scipy.integrate.solve_ivp RK23 max_step 0.01 to t = {} '
+                '({} evaluations in {:.2f} s) over the NumPy restatement of the '
+                'right-hand side: the reference\'s own execution shape'
+                .format(t_end, nfev, ref_elapsed)}
   return {
       'value': points / elapsed, 'unit': 'grid-point-steps/s', 'cores': threads,
       'kind': 'port',
@@ -117,6 +133,7 @@ def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
                 'forcing on the reference grid, same RK scheme), batch {} x {} '
                 'steps in {:.1f} s on {} threads; host has {} logical cores'
                 .format(sample, steps, elapsed, threads, os.cpu_count()),
+      'reference_style': reference_style,
   }
 
 
