@@ -436,6 +436,10 @@ int spec_equation(const ddd_model* m) {
   if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
   if ((dp.conservative != 0) != ddd::mfma::spec_flux_form(dp.equation)) return -1;
   if ((dp.folded != 0) != (dp.D <= 2)) return -1;
+  // the three-derivative kernels hard-wire the null-space split 5 + 4 + 2
+  if (dp.D == 3 && !(dp.in_size[0] == 5 && dp.in_size[1] == 4 && dp.in_size[2] == 2 &&
+                     dp.in_start[0] == 0 && dp.in_start[1] == 5 && dp.in_start[2] == 9))
+    return -1;
   return dp.equation;
 }
 

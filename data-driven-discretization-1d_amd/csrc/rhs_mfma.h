@@ -632,21 +632,24 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      if (!((p.dsel_valid >> c) & 1u)) continue;
-      const unsigned d = (p.dsel_bits >> (2 * c)) & 3u;
+      // specialised three-derivative (KS) kernels: null-space sizes 5 + 4 + 2 at
+      // polynomial accuracy order 1 (checked by capi.hip: spec_equation), so the
+      // channel -> derivative map is a compile-time constant
+      if (kSpec ? c >= 11 : !((p.dsel_valid >> c) & 1u)) continue;
+      const unsigned d = kSpec ? (c < 5 ? 0u : c < 9 ? 1u : 2u) : (p.dsel_bits >> (2 * c)) & 3u;
       const float nv = net[c];
       const float4 n0 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax);
       const float4 n1 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax + 4);
       const float nsr[kGMax] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
       if (d == 0) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
+        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
       } else if (d == 1) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
+        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
       } else if (d == 2) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
+        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
       } else {
 #pragma unroll
         for (int g = 0; g < kGMax; ++g) cf[3][g] = fmaf(nv, nsr[g], cf[3][g]);
