@@ -272,7 +272,7 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     m->dp.folded = 0;
     const char* nofold = std::getenv("DDD_NO_FOLD");
     if (dp.D <= 2 && !(nofold != nullptr && nofold[0] == '1')) {
-      // Fold coeff_delta = net[start:stop] @ nullspace into the output layer:
+      // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
       // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
       // (accumulated in double, rounded once to float32), same for the bias.
       // The layer then emits the D x 8 coefficient deltas directly and the
@@ -291,7 +291,9 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
                      (double)dp.ns8[dp.in_start[d] + j][g];
             wf[(size_t)tc * 16 + oc] = (float)acc;
           }
-          double acc = 0.0;
+          // bias row of the folded layer: the accuracy layer's standard
+          // coefficients + the projected conv bias, rounded once
+          double acc = (double)dp.bias8[d][g];
           for (int j = 0; j < dp.in_size[d]; ++j)
             acc += (double)b_nat[dp.in_start[d] + j] * (double)dp.ns8[dp.in_start[d] + j][g];
           bf[oc] = (float)acc;

@@ -662,7 +662,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     dv[d] = 0.0f;
     if (d < nD) {
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
+      for (int g = 0; g < kGMax; ++g)   // folded: the bias rides in the output layer's bias row
+        if (!folded) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
       if (coeffs_out != nullptr && ln.active) {
         float* dst = coeffs_out + ((size_t)ln.gidx * nD + d) * nG;
 #pragma unroll
