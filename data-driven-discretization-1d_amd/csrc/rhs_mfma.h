@@ -203,11 +203,16 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
   if (act == ACT_RELU) {
-    // one v_med3_f32 per element: med3(x, 0, +inf) == max(x, 0) for every
-    // non-NaN x (fmaxf would cost an extra canonicalising v_max)
+    // ONE v_max_f32 per element.  fmaxf / fmed3 builtins make the compiler
+    // prepend a canonicalising v_max x, x (it cannot prove an MFMA result is
+    // not a signalling NaN), doubling the VALU work of every layer boundary,
+    // where the matrix pipe is idle; max(0, NaN) = 0 either way.
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc[r] = __builtin_amdgcn_fmed3f(acc[r], 0.0f, __builtin_inff());
+    for (int r = 0; r < 16; ++r) {
+      float y;
+      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(acc[r]));
+      acc[r] = y;
+    }
   } else if (act == ACT_RELU6) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
