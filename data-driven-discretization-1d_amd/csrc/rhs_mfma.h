@@ -291,16 +291,16 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
-  // 32-bit float offsets (not pointers: pointer arrays make the compiler carry
+  // 32-bit byte offsets (not pointers: pointer arrays make the compiler carry
   // 64-bit address arithmetic for what ends up as an LDS offset)
   int rowo[kT][kKW];
 #pragma unroll
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)kHS) + 16 * half;   // rows < 256
-  const auto operand = [&](int t, int tap, int q) {
-    return *reinterpret_cast<const float4*>(in + rowo[t][tap] + 4 * q);
+      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) + 64 * half;   // bytes; rows < 256
+  const auto operand = [&](int t, int tap, int q) {   // one v_mad_u32_u24 per row, q in the DS offset field
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) + rowo[t][tap] + 16 * q);
   };
   f32x16 acc[kT];
   float4 cur[kT], nxt[kT];
@@ -371,14 +371,14 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
   // accumulators are independent chains issued round-robin (a dependent
   // 16x16x4 needs 40 cycles, the pipe takes one every 32), and the reads of
   // group g + 1 are issued before the MFMAs of group g.
-  int rowo[kT][kKW];   // 32-bit float offsets, see hidden_layer
+  int rowo[kT][kKW];   // 32-bit byte offsets, see hidden_layer
 #pragma unroll
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)kHS) + 8 * quarter;
+      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) + 32 * quarter;   // bytes
   const auto operand = [&](int t, int tap, int q) {
-    return *reinterpret_cast<const float4*>(in + rowo[t][tap] + 4 * q);
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) + rowo[t][tap] + 16 * q);
   };
   f32x4 acc[kT];
   float4 cur[kT], nxt[kT];
