@@ -422,7 +422,10 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
 }
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
+constexpr int kFinKeep = kFinSteps;   // output-layer weight registers kept for the whole launch (see eval_rhs)
+
 struct Resident {
+  float w_fin[kFinKeep];    // the first kFinKeep output-layer weights (specialised one-wave kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
@@ -549,6 +552,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   for (int c = 0; c < 16; ++c) net[c] = 0.0f;
   if (!fixed) {
     float wfin[kFinSteps];
+    // specialised one-wave kernels (D <= 2) have spare registers: part of the
+    // output layer's weights stays resident, the rest is fetched per evaluation
+    constexpr int kKept = (kOneWave && kHoist && kEq >= 0 && spec_derivs(kEq) <= 2) ? kFinKeep : 0;
+#pragma unroll
+    for (int s2 = 0; s2 < kKept; ++s2) wfin[s2] = res.w_fin[s2];
     DDD_STAMP(1);
     if (!(ablate & 16))
       input_layer<kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act);
@@ -571,7 +579,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     {
       const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
 #pragma unroll
-      for (int s2 = kFinPrefetch; s2 < kFinSteps; ++s2) wfin[s2] = wsrc[s2 * 64];
+      for (int s2 = (kKept > kFinPrefetch ? kKept : kFinPrefetch); s2 < kFinSteps; ++s2)
+        wfin[s2] = wsrc[s2 * 64];
     }
     // the output layer's weights are in flight from L2 and the hidden layer's
     // last activations on their way to LDS: fill the wait with the forcing
@@ -751,6 +760,8 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
 #pragma unroll
     for (int s = 0; s < kInSteps; ++s) res.w_in[s] = p.w_input[s * 64 + ln.lane];
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
+#pragma unroll
+    for (int s = 0; s < kFinKeep; ++s) res.w_fin[s] = p.w_final[s * 64 + ln.lane];
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
   res.fk_next = 0.0f;
