@@ -357,7 +357,9 @@ __device__ __forceinline__ void load_final(const DevParams& p, int lane,
   for (int s = 0; s < kFinSteps; ++s) w[s] = src[s * 64];
 }
 
-template <int kWR>
+// kByteOffsets: `rows` already holds the LDS byte offsets of the operand rows
+// (kept resident by the specialised one-wave kernels) instead of row numbers.
+template <int kWR, bool kByteOffsets>
 __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ in,
                                             float* __restrict__ out,
@@ -376,7 +378,9 @@ __device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) + 32 * quarter;   // bytes
+      rowo[t][tap] = kByteOffsets ? rows[t][tap]
+                                  : (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) +
+                                        32 * quarter;   // bytes
   const auto operand = [&](int t, int tap, int q) {
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) + rowo[t][tap] + 16 * q);
   };
@@ -426,6 +430,7 @@ constexpr int kFinKeep = kFinSteps;   // output-layer weight registers kept for 
 
 struct Resident {
   float w_fin[kFinKeep];    // the first kFinKeep output-layer weights (specialised one-wave kernels)
+  int fin_off[4][kKW];      // LDS byte offsets of the output layer's operand rows (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
@@ -507,6 +512,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const int nL = kHoist ? 3 : p.L;
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
+  // specialised one-wave kernels (D <= 2) have spare registers for loop invariants
+  constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0 && spec_derivs(kEq) <= 2;
   const int tid = opaque((int)threadIdx.x);
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid);
   if (ln.owner) sm.u[ln.row] = u;
@@ -518,9 +525,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
     for (int t2 = 0; t2 < kWR / 32; ++t2)
       tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
+    if (!kKeepRows) {
 #pragma unroll
-    for (int t2 = 0; t2 < kWR / 16; ++t2)
-      tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
+      for (int t2 = 0; t2 < kWR / 16; ++t2)
+        tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
+    } else {
+#pragma unroll
+      for (int t2 = 0; t2 < 4; ++t2)
+#pragma unroll
+        for (int k = 0; k < kKW; ++k) fin_rows[t2][k] = res.fin_off[t2][k];
+    }
   }
   const float un_reg = u / p.stddev;   // model.py:450-451, a true division
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
@@ -588,7 +602,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
     if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
     __syncthreads();
-    final_layer<kWR>(p, ln, in, out, wfin, fin_rows);
+    final_layer<kWR, kKeepRows>(p, ln, in, out, wfin, fin_rows);
     DDD_STAMP(3);
     __syncthreads();
     const float4* nrow = reinterpret_cast<const float4*>(out + ln.row * kHS);
@@ -762,6 +776,17 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
 #pragma unroll
     for (int s = 0; s < kFinKeep; ++s) res.w_fin[s] = p.w_final[s * 64 + ln.lane];
+    if (kRows == 64 && kWR == 64) {
+#pragma unroll
+      for (int t2 = 0; t2 < 4; ++t2) {
+        int rows[kKW];
+        tap_rows<true>(ln, t2 * 16 + (ln.lane & 15), p.N, rows);
+#pragma unroll
+        for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
+          res.fin_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
+                                      32 * (ln.lane >> 4));
+      }
+    }
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
   res.fk_next = 0.0f;
