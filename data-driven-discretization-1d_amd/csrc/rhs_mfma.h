@@ -431,6 +431,7 @@ constexpr int kFinKeep = kFinSteps;   // output-layer weight registers kept for 
 struct Resident {
   float w_fin[kFinKeep];    // the first kFinKeep output-layer weights (specialised one-wave kernels)
   int fin_off[4][kKW];      // LDS byte offsets of the output layer's operand rows (same kernels)
+  int pch_idx[kGMax];       // indices into Shared::u of this row's stencil patch (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
@@ -645,8 +646,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < nG) ? sm.u[pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
-                                    : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
+      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g]
+                               : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                      : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
   float cf[kMaxDerivs][kGMax];
 #pragma unroll
@@ -786,6 +788,10 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
           res.fin_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
                                       32 * (ln.lane >> 4));
       }
+      const int gl = p.G >> 1;
+#pragma unroll
+      for (int g = 0; g < kGMax; ++g)
+        res.pch_idx[g] = opaque(((ln.pos + g - gl) & (p.N - 1)) | ln.base);
     }
   }
   res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
