@@ -776,9 +776,11 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
 #pragma unroll
     for (int s = 0; s < kInSteps; ++s) res.w_in[s] = p.w_input[s * 64 + ln.lane];
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
+    // loop invariants the specialised one-wave integrators keep resident
+    // (kHoist: the persistent kernels; a single fused substep has no loop)
+    if (kHoist && kRows == 64 && kWR == 64) {
 #pragma unroll
-    for (int s = 0; s < kFinKeep; ++s) res.w_fin[s] = p.w_final[s * 64 + ln.lane];
-    if (kRows == 64 && kWR == 64) {
+      for (int s = 0; s < kFinKeep; ++s) res.w_fin[s] = p.w_final[s * 64 + ln.lane];
 #pragma unroll
       for (int t2 = 0; t2 < 4; ++t2) {
         int rows[kKW];
