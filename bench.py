@@ -4,15 +4,34 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+    (`python bench.py --gpus N` without a torchrun environment re-launches
+    itself under torch.distributed.run on 127.0.0.1)
 
-Workload (BASELINE.json configs[1]): Burgers N=64, learned conv-net stencils
-(3 layers x 32 filters x kernel 5, conservative form, polynomial accuracy
-order 1), batch = 1024 random-phase initial conditions PER GPU with per-sample
-random forcing, fixed-step midpoint rule at the equation's time step (the
-reference's batched integrator, model.integrate_ode, model.py:138-159).
-A "step" is one full Runge-Kutta step of the whole batch; one grid-point-step =
-one grid point advanced by one step.  Weights are
-synthetic (Glorot, seeded); inputs are resident in HBM before timing starts.
+Workload = BASELINE.json's north_star target configuration: Burgers N=64,
+learned conv-net stencils (3 layers x 32 filters x kernel 5, conservative
+form, polynomial accuracy order 1), batch = 4096 random-phase initial
+conditions PER GPU with per-sample random forcing, fixed-step midpoint rule at
+the equation's time step (the reference's batched integrator,
+model.integrate_ode, model.py:138-159).  BASELINE.json configs[1] (the same
+model at batch 1024) is measured in the same run and reported under
+"secondary".  A "step" is one full Runge-Kutta step of the whole batch; one
+grid-point-step = one grid point advanced by one step.
+Weights are synthetic (Glorot, seeded); inputs are resident in HBM before
+timing starts.
+
+Timing protocol (every rank):
+  1. pre-heat: the SAME kernel runs back to back for >= --preheat-ms (default
+     300 ms), independent of --warmup, so that a short timed region does not
+     run at ramping clocks / with a cold code object;
+  2. --warmup W untimed steps (one launch);
+  3. barrier + synchronize; the timed region is R back-to-back jobs of exactly
+     --steps K steps each (every job: one persistent launch from the same y0 +,
+     for N > 1, the RCCL all-gather of the final states); R = 1 when one job
+     lasts >= --min-timed-ms (default 40 ms), otherwise the smallest R that
+     fills it.  R is reported as "reps"; "ms_per_step" and "value" are means
+     over the R*K timed steps, "roofline.kernel_ms_per_launch" the HIP-event
+     time of the launches divided by their number;
+  4. synchronize + barrier; wall = max over ranks.
 
 With N > 1 every rank integrates its own shard of the ensemble (weak scaling,
 no communication during stepping) and the final states are all-gathered over
@@ -22,9 +41,14 @@ Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline and
 cpu_baseline definitions.
 """
 import argparse
+import glob
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,30 +58,42 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
+TRAFFIC_TABLES = ('r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
 
 
-def parse_args():
+def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=1000)
   ap.add_argument('--warmup', type=int, default=100)
-  ap.add_argument('--batch', type=int, default=1024, help='samples per GPU')
+  ap.add_argument('--batch', type=int, default=4096, help='samples per GPU')
+  ap.add_argument('--secondary-batch', type=int, default=1024,
+                  help='second batch size measured in the same run at N=1 '
+                       '(BASELINE.json configs[1]); 0 disables')
   ap.add_argument('--num-points', type=int, default=64)
   ap.add_argument('--equation', default='burgers')
   ap.add_argument('--scheme', default='midpoint',
                   choices=['euler', 'midpoint', 'bs3', 'rk4'])
   ap.add_argument('--launch-mode', default='persistent',
                   choices=['persistent', 'per_substep'])
+  ap.add_argument('--state-dtype', default='float32', choices=['float32', 'float64'],
+                  help='float64: state and RK update in f64, right-hand side in f32 '
+                       '(the reference SciPy path, integrate.py:154)')
   ap.add_argument('--non-conservative', action='store_true')
   ap.add_argument('--baseline-stencils', action='store_true',
                   help='fixed polynomial stencils instead of the conv net')
-  ap.add_argument('--kernel', default='auto', choices=['auto', 'mfma', 'mfma64', 'mfma64w32', 'mfma256', 'generic'])
+  ap.add_argument('--kernel', default='auto',
+                  choices=['auto', 'mfma', 'mfma64', 'mfma64w32', 'mfma256', 'generic'])
+  ap.add_argument('--preheat-ms', type=float, default=300.0,
+                  help='run the timed kernel this long before --warmup (0 disables)')
+  ap.add_argument('--min-timed-ms', type=float, default=40.0,
+                  help='repeat the K-step job until the timed region lasts this long')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
-  return ap.parse_args()
+  return ap.parse_args(argv)
 
 
-def build_workload(args, rank):
+def build_workload(args, rank, batch):
   import ddd1d_amd
   from ddd1d_amd import equations, model as model_lib
   rf = 8
@@ -73,7 +109,7 @@ def build_workload(args, rank):
   model.set_kernel(args.kernel)
   # sample ids are global: rank r owns ids [r*batch, (r+1)*batch)
   from ddd1d_amd import distributed
-  seeds = distributed.weak_shard_ids(args.batch, rank)
+  seeds = distributed.weak_shard_ids(batch, rank)
   forcing = model_lib.batched_forcing_parameters(seeds, nparams=20)
   model.set_forcing(forcing)
   ic = model_lib.batched_forcing_parameters(
@@ -137,41 +173,92 @@ def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
   }
 
 
-def main():
-  args = parse_args()
+class ClockSampler(object):
+  """Samples the shader clock and socket power of one GPU from sysfs (amdgpu
+  hwmon: freq1_input [Hz], power1_average / power1_input [uW]) in a background
+  thread while the kernel runs: evidence for the sustained-clock figure in
+  DESIGN.md.  Silent (returns None) where the files do not exist."""
+
+  def __init__(self, device_index=0, period_s=0.005):
+    self.period = period_s
+    self.samples = []
+    self._stop = threading.Event()
+    self._thread = None
+    self.freq_path, self.power_path = self._find(device_index)
+
+  @staticmethod
+  def _find(device_index):
+    cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'),
+                   key=lambda p: int(p.split('/card')[1].split('/')[0]))
+    cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
+    if device_index >= len(cards):
+      return None, None
+    base = cards[device_index]
+    power = None
+    for name in ('power1_average', 'power1_input'):
+      if os.path.exists(os.path.join(base, name)):
+        power = os.path.join(base, name)
+        break
+    return os.path.join(base, 'freq1_input'), power
+
+  @staticmethod
+  def _read(path):
+    try:
+      with open(path) as f:
+        return float(f.read().strip())
+    except (OSError, ValueError):
+      return None
+
+  def _loop(self):
+    while not self._stop.is_set():
+      freq = self._read(self.freq_path)
+      power = self._read(self.power_path) if self.power_path else None
+      self.samples.append((time.perf_counter(), freq, power))
+      time.sleep(self.period)
+
+  def start(self):
+    if self.freq_path is None:
+      return self
+    self._thread = threading.Thread(target=self._loop, daemon=True)
+    self._thread.start()
+    return self
+
+  def stop(self, t_begin=None, t_end=None):
+    if self._thread is None:
+      return None
+    self._stop.set()
+    self._thread.join()
+    rows = [s for s in self.samples
+            if (t_begin is None or s[0] >= t_begin) and (t_end is None or s[0] <= t_end)]
+    freqs = [s[1] / 1e6 for s in rows if s[1]]
+    powers = [s[2] / 1e6 for s in rows if s[2]]
+    if not freqs:
+      return None
+    out = {'source': self.freq_path, 'samples': len(freqs),
+           'sclk_mhz_mean': sum(freqs) / len(freqs), 'sclk_mhz_min': min(freqs),
+           'sclk_mhz_max': max(freqs)}
+    if powers:
+      out.update(power_w_mean=sum(powers) / len(powers), power_w_max=max(powers))
+    return out
+
+
+def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
+  """Pre-heat, warm-up and the timed region for one (model, batch).  Returns
+  wall seconds, HIP-event milliseconds, repetitions and bookkeeping; all ranks
+  must call it together."""
   import torch
   import torch.distributed as dist
-
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  if world != args.gpus:
-    if world == 1 and args.gpus > 1:
-      raise SystemExit('launch with torch.distributed.run --nproc-per-node {}'
-                       .format(args.gpus))
-    raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
-  torch.cuda.set_device(local_rank)
-  if world > 1:
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-
-  import ddd1d_amd
-  ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
-  eq, model, forcing, y0_host = build_workload(args, rank)
-  lib = ddd1d_amd._lib.load_library()
-  stages = lib.ddd_scheme_stages(ddd1d_amd._lib.SCHEMES[args.scheme])
-  dt = eq.time_step
-  n = eq.grid.solution_num_points
-  batch = args.batch
-
-  y0 = torch.from_numpy(y0_host).cuda()
-  final = torch.empty((1, batch, n), dtype=torch.float32, device='cuda')
-  gathered = (torch.empty((world, batch, n), dtype=torch.float32, device='cuda')
+  dt = model.equation.time_step
+  dtype = torch.float64 if args.state_dtype == 'float64' else torch.float32
+  y0 = torch.from_numpy(y0_host).cuda().to(dtype)
+  final = torch.empty((1, batch, n), dtype=dtype, device='cuda')
+  gathered = (torch.empty((world, batch, n), dtype=dtype, device='cuda')
               if world > 1 else None)
 
-  def run(num_steps, t0):
-    model.integrate_fixed(y0, num_steps, dt=dt, t0=t0, scheme=args.scheme,
+  def job(num_steps):
+    model.integrate_fixed(y0, num_steps, dt=dt, t0=0.0, scheme=args.scheme,
                           save_every=num_steps, launch_mode=args.launch_mode,
-                          out=final)
+                          state_dtype=args.state_dtype, out=final)
     if world > 1:
       dist.all_gather_into_tensor(gathered, final[0])
 
@@ -180,56 +267,182 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
-  if args.warmup > 0:
-    run(args.warmup, 0.0)
-  barrier()
   start_evt = torch.cuda.Event(enable_timing=True)
   stop_evt = torch.cuda.Event(enable_timing=True)
-  wall0 = time.perf_counter()
-  start_evt.record()
-  model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
-                        save_every=args.steps, launch_mode=args.launch_mode,
-                        out=final)
-  stop_evt.record()
+  sampler = ClockSampler(torch.cuda.current_device()).start() if sample_clocks else None
+
+  # 1. pre-heat with the timed kernel itself (clocks, code object, L2)
+  heat_steps = max(args.steps, 200)
+  step_ms = None
+  heated = 0.0
+  heat_launches = 0
+  while heated < args.preheat_ms or step_ms is None:
+    start_evt.record()
+    model.integrate_fixed(y0, heat_steps, dt=dt, t0=0.0, scheme=args.scheme,
+                          save_every=heat_steps, launch_mode=args.launch_mode,
+                          state_dtype=args.state_dtype, out=final)
+    stop_evt.record()
+    torch.cuda.synchronize()
+    ms = start_evt.elapsed_time(stop_evt)
+    heated += ms
+    heat_launches += 1
+    step_ms = ms / heat_steps
+    if args.preheat_ms <= 0 or heat_launches >= 10000:
+      break
+  # repetitions: agreed across ranks (rank 0's estimate)
+  reps = max(1, int(math.ceil(args.min_timed_ms / max(step_ms * args.steps, 1e-6))))
+  reps = min(reps, 100000)
   if world > 1:
-    dist.all_gather_into_tensor(gathered, final[0])
+    r = torch.tensor([reps], dtype=torch.int64, device='cuda')
+    dist.broadcast(r, 0)
+    reps = int(r[0])
+
+  # 2. the contract's warm-up steps
+  if args.warmup > 0:
+    job(args.warmup)
+  # 3. timed region
   barrier()
-  wall = time.perf_counter() - wall0
-  kernel_ms = start_evt.elapsed_time(stop_evt)   # events on the launch stream
+  wall0 = time.perf_counter()
+  # one event pair per launch: kernel_ms is launch time only (no collective,
+  # no inter-launch gap), on the stream the kernel is launched on
+  evts = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(reps)]
+  for e0, e1 in evts:
+    e0.record()
+    model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
+                          save_every=args.steps, launch_mode=args.launch_mode,
+                          state_dtype=args.state_dtype, out=final)
+    e1.record()
+    if world > 1:
+      dist.all_gather_into_tensor(gathered, final[0])
+  barrier()
+  wall1 = time.perf_counter()
+  wall = wall1 - wall0
+  kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evts)
+  clocks = sampler.stop(wall0, wall1) if sampler is not None else None
 
   if world > 1:
     t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, kernel_ms = float(t[0]), float(t[1])
-
   finite = bool(torch.isfinite(final).all())
+  return dict(wall=wall, kernel_ms=kernel_ms, reps=reps, finite=finite,
+              preheat_ms=heated, preheat_launches=heat_launches, clocks=clocks)
+
+
+def summarize(args, eq, model, m, world, n, batch, stages):
+  """Throughput + roofline numbers for one measurement."""
+  steps_timed = args.steps * m['reps']
+  total_points = batch * n * steps_timed * world
+  fma = model.fma_per_point
+  launches_per_job = 1 if args.launch_mode == 'persistent' else args.steps * stages
+  launches = launches_per_job * m['reps']
+  flops_per_launch = 2.0 * fma * batch * n * stages * args.steps / launches_per_job
+  state_bytes = 8.0 if args.state_dtype == 'float32' else 16.0   # in + out per point
+  bytes_per_launch = (state_bytes * batch * n if args.launch_mode == 'persistent' else
+                      (20.0 if args.scheme == 'midpoint' else 8.0 * stages)
+                      * batch * n / stages)
+  launch_s = m['kernel_ms'] * 1e-3 / launches
+  achieved_tflops = flops_per_launch / launch_s / 1e12
+  achieved_gbps = bytes_per_launch / launch_s / 1e9
+  compute_bound = not args.baseline_stencils
+  traffic, traffic_source = measured_traffic(
+      type(eq).__name__, n, batch, args.launch_mode, args.baseline_stencils,
+      state_dtype=args.state_dtype)
+  roofline = {
+      'bound': 'mfma' if compute_bound else 'hbm',
+      'achieved': achieved_tflops if compute_bound else achieved_gbps,
+      'peak': PEAK_FP32_TFLOPS if compute_bound else PEAK_HBM_GBPS,
+      'unit': 'TFLOP/s' if compute_bound else 'GB/s',
+      'frac': (achieved_tflops / PEAK_FP32_TFLOPS if compute_bound
+               else achieved_gbps / PEAK_HBM_GBPS),
+      'traffic': traffic,
+      'traffic_source': traffic_source,
+      'kernel_ms_per_launch': m['kernel_ms'] / launches,
+      'launches': launches,
+      'hbm_gbps': achieved_gbps,
+      'hbm_frac': achieved_gbps / PEAK_HBM_GBPS,
+      'fp32_tflops': achieved_tflops,
+      'fp32_frac': achieved_tflops / PEAK_FP32_TFLOPS,
+  }
+  return {
+      'value': total_points / m['wall'],
+      'ms_per_step': m['wall'] * 1e3 / steps_timed,
+      'roofline': roofline,
+  }
+
+
+def relaunch_under_torchrun(args):
+  """`python bench.py --gpus N` outside a torchrun environment: start the N
+  ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)."""
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+         '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+  return subprocess.call(cmd, env=env)
+
+
+def main():
+  args = parse_args()
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if 'RANK' not in os.environ and args.gpus > 1:
+    raise SystemExit(relaunch_under_torchrun(args))
+  if world != args.gpus:
+    raise SystemExit('--gpus {} but WORLD_SIZE {}'.format(args.gpus, world))
+  import torch
+  import torch.distributed as dist
+
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  torch.cuda.set_device(local_rank)
+  if world > 1:
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+  import ddd1d_amd
+  lib = ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
+  stages = lib.ddd_scheme_stages(ddd1d_amd._lib.SCHEMES[args.scheme])
+  batch = args.batch
+  eq, model, forcing, y0_host = build_workload(args, rank, batch)
+  dt = eq.time_step
+  n = eq.grid.solution_num_points
+
+  m = measure(args, model, y0_host, world, n, batch, sample_clocks=(rank == 0))
+  secondary = None
+  if world == 1 and args.secondary_batch > 0 and args.secondary_batch != batch:
+    b2 = args.secondary_batch
+    eq2, model2, _, y02 = build_workload(args, rank, b2)
+    m2 = measure(args, model2, y02, world, n, b2)
+    s2 = summarize(args, eq2, model2, m2, world, n, b2, stages)
+    secondary = {
+        'workload': 'BASELINE.json configs[1] batch' if b2 == 1024 else 'secondary batch',
+        'batch_per_gpu': b2, 'value': s2['value'], 'unit': 'grid-point-steps/s',
+        'ms_per_step': s2['ms_per_step'], 'reps': m2['reps'],
+        'fp32_tflops': s2['roofline']['fp32_tflops'],
+        'frac': s2['roofline']['frac'],
+        'kernel_ms_per_launch': s2['roofline']['kernel_ms_per_launch'],
+        'kernel': model2.kernel_name, 'finite': m2['finite'],
+    }
+
   if rank == 0:
-    points_per_gpu = batch * n * args.steps
-    total_points = points_per_gpu * world
-    fma = model.fma_per_point
-    launches = 1 if args.launch_mode == 'persistent' else args.steps * stages
-    flops_per_launch = 2.0 * fma * batch * n * stages * args.steps / launches
-    bytes_per_launch = (8.0 * batch * n if args.launch_mode == 'persistent' else
-                        (20.0 if args.scheme == 'midpoint' else 8.0 * stages)
-                        * batch * n / stages)
-    launch_s = kernel_ms * 1e-3 / launches
-    achieved_tflops = flops_per_launch / launch_s / 1e12
-    achieved_gbps = bytes_per_launch / launch_s / 1e9
-    compute_bound = not args.baseline_stencils
-    traffic = measured_traffic(type(eq).__name__, n, batch, args.launch_mode,
-                               args.baseline_stencils)
+    s = summarize(args, eq, model, m, world, n, batch, stages)
+    dtype = 'f32' if args.state_dtype == 'float32' else 'f32 rhs / f64 state'
     result = {
         'metric': 'grid-point-steps/s',
-        'value': total_points / wall,
+        'value': s['value'],
         'unit': 'grid-point-steps/s',
         'n_gpus': world,
         'steps': args.steps,
         'warmup': args.warmup,
-        'ms_per_step': wall * 1e3 / args.steps,
+        'reps': m['reps'],
+        'ms_per_step': s['ms_per_step'],
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': dtype,
         'data': 'synthetic',
         'config': {
             'workload': '{} N={} {} learned-stencil ensemble, batch {}/GPU, '
@@ -241,24 +454,16 @@ def main():
             'batch_per_gpu': batch, 'global_batch': batch * world,
             'scheme': args.scheme, 'stages': stages, 'dt': dt,
             'launch_mode': args.launch_mode, 'kernel': model.kernel_name,
-            'fma_per_point_eval': fma, 'parallelism': 'ensemble-shard x{}'.format(world),
-            'finite': finite,
+            'state_dtype': args.state_dtype,
+            'fma_per_point_eval': model.fma_per_point,
+            'parallelism': 'ensemble-shard x{}'.format(world),
+            'finite': m['finite'],
+            'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,
+            'timed_wall_ms': m['wall'] * 1e3,
         },
-        'roofline': {
-            'bound': 'mfma' if compute_bound else 'hbm',
-            'achieved': achieved_tflops if compute_bound else achieved_gbps,
-            'peak': PEAK_FP32_TFLOPS if compute_bound else PEAK_HBM_GBPS,
-            'unit': 'TFLOP/s' if compute_bound else 'GB/s',
-            'frac': (achieved_tflops / PEAK_FP32_TFLOPS if compute_bound
-                     else achieved_gbps / PEAK_HBM_GBPS),
-            'traffic': traffic,
-            'kernel_ms_per_launch': kernel_ms / launches,
-            'launches': launches,
-            'hbm_gbps': achieved_gbps,
-            'hbm_frac': achieved_gbps / PEAK_HBM_GBPS,
-            'fp32_tflops': achieved_tflops,
-            'fp32_frac': achieved_tflops / PEAK_FP32_TFLOPS,
-        },
+        'roofline': s['roofline'],
+        'secondary': secondary,
+        'clocks': m['clocks'],
     }
     if world == 1 and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(model, forcing, y0_host, args.scheme,
@@ -270,24 +475,30 @@ def main():
     dist.destroy_process_group()
 
 
-def measured_traffic(equation, num_points, batch, launch_mode, fixed):
-  """HBM bytes per launch of the dominant kernel from the committed rocprofv3
-  PMC passes (FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction
-  applied; profiles/r1_hbm_traffic.json), or None when this configuration was
-  not profiled.  bench.py cannot collect counters itself."""
-  path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                      'r1_hbm_traffic.json')
-  try:
-    with open(path) as f:
-      table = json.load(f)
-  except (OSError, ValueError):
-    return None
+def measured_traffic(equation, num_points, batch, launch_mode, fixed, state_dtype='float32'):
+  """(HBM bytes per launch of the dominant kernel, source file) from the
+  committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
+  runs, gfx950 correction applied; profiles/r*_hbm_traffic.json), or
+  (None, None) when this configuration was not profiled.  bench.py cannot
+  collect counters itself; the table entry names the command it was measured
+  with.  In persistent mode one launch reads y0 + forcing rows + weights and
+  writes one snapshot whatever --steps is, so entries are keyed on the
+  configuration, not on the step count; per-substep entries are per substep."""
   want = dict(equation=equation, num_points=num_points, batch_per_gpu=batch,
               launch_mode=launch_mode, fixed=bool(fixed))
-  for entry in table.get('entries', []):
-    if entry.get('match') == want:
-      return entry['traffic_bytes_per_launch']
-  return None
+  if state_dtype != 'float32':
+    want['state_dtype'] = state_dtype
+  for name in TRAFFIC_TABLES:
+    path = os.path.join(ROOT, 'profiles', name)
+    try:
+      with open(path) as f:
+        table = json.load(f)
+    except (OSError, ValueError):
+      continue
+    for entry in table.get('entries', []):
+      if entry.get('match') == want:
+        return entry['traffic_bytes_per_launch'], 'profiles/' + name
+  return None, None
 
 
 if __name__ == '__main__':

@@ -1301,8 +1301,13 @@ int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* tic
   for (int rep = 0; rep < 2; ++rep) {
     DDD_HIP(hipEventRecord(e0, nullptr));
 #define DDD_RATE(C, W) hipLaunchKernelGGL((ddd::ops::mfma_rate_probe_kernel<C, W>), dim3(blocks), dim3(64), 0, nullptr, d, iters, 1.0f)
-    if (is32) { if (chains == 1) DDD_RATE(1, true); else if (chains == 2) DDD_RATE(2, true); else DDD_RATE(4, true); }
+#define DDD_RATE4(C) hipLaunchKernelGGL((ddd::ops::mfma4_rate_probe_kernel<C>), dim3(blocks), dim3(64), 0, nullptr, d, iters, 1.0f)
+    if (is32 == 2) {   // v_mfma_f32_4x4x1_16b_f32, 24 per iteration
+      if (chains == 1) DDD_RATE4(1); else if (chains == 2) DDD_RATE4(2);
+      else if (chains == 3) DDD_RATE4(3); else DDD_RATE4(4);
+    } else if (is32) { if (chains == 1) DDD_RATE(1, true); else if (chains == 2) DDD_RATE(2, true); else DDD_RATE(4, true); }
     else { if (chains == 1) DDD_RATE(1, false); else if (chains == 2) DDD_RATE(2, false); else DDD_RATE(4, false); }
+#undef DDD_RATE4
 #undef DDD_RATE
     DDD_HIP(hipEventRecord(e1, nullptr));
     DDD_HIP(hipEventSynchronize(e1));
@@ -1314,8 +1319,9 @@ int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* tic
   (void)hipFree(d);
   double sum = 0.0;
   for (int b = 0; b < blocks; ++b) sum += (double)h[(size_t)b * 2];
-  *ticks_per_mfma = sum / blocks / ((double)iters * 8.0);
-  *wall_ns_per_mfma = (double)ms * 1e6 / ((double)iters * 8.0);
+  const double per_iter = is32 == 2 ? 24.0 : 8.0;
+  *ticks_per_mfma = sum / blocks / ((double)iters * per_iter);
+  *wall_ns_per_mfma = (double)ms * 1e6 / ((double)iters * per_iter);
   return DDD_OK;
 }
 
@@ -1351,6 +1357,27 @@ int ddd_selftest_mfma_layout(void) {
                     "mfma_f32_16x16x4 layout mismatch at D[%d][%d]: got %g want %g", i, j,
                     h16[i * 16 + j], want);
     }
+  {
+    // 4x4x1 (16 blocks) with the A block broadcast: register r of lane l must be
+    // A(lane 4 abid + r) * B(lane l) + C   (ops.h: mfma4_bcast)
+    float* d4 = nullptr;
+    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d4), 16 * 4 * 64 * sizeof(float)));
+    hipLaunchKernelGGL(ddd::ops::mfma4_layout_probe_kernel, dim3(1), dim3(64), 0, nullptr, d4);
+    DDD_HIP(hipGetLastError());
+    std::vector<float> h4(16 * 4 * 64);
+    DDD_HIP(hipMemcpy(h4.data(), d4, h4.size() * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d4);
+    for (int abid = 0; abid < 16; ++abid)
+      for (int r = 0; r < 4; ++r)
+        for (int l = 0; l < 64; ++l) {
+          const float want = fmaf((float)(1000 * abid + r + 1), (float)(l + 1), 0.5f);
+          const float got = h4[(abid * 4 + r) * 64 + l];
+          if (got != want)
+            return fail(DDD_ERR_UNSUPPORTED,
+                        "mfma_f32_4x4x1 broadcast layout mismatch at abid %d reg %d lane %d: "
+                        "got %g want %g", abid, r, l, got, want);
+        }
+  }
   // informational: the kernels fall back to ds_bpermute when this is 0
   (void)dpp_wave_rol_ok();
   return DDD_OK;

@@ -187,6 +187,32 @@ __global__ void mfma_layout_probe_kernel(float* __restrict__ out32,
   }
 }
 
+// v_mfma_f32_4x4x1_16b_f32 with A-block broadcast (cbsz = 4: block `abid` of the A
+// register feeds all 16 blocks).  ASSUMED layout, checked by ddd_selftest_mfma_layout:
+//   A: lane l holds A[i = l & 3] of block l >> 2;  B: lane l holds B[j = l & 3] of block l >> 2;
+//   D: register r of lane l is D[i = r][j = l & 3] of block l >> 2
+// so with the broadcast, register r of lane l = A(lane 4 abid + r) * B(lane l) + C:
+// every lane keeps its OWN column -- four output channels of its own grid point.
+template <int kAbid>
+__device__ __forceinline__ f32x4 mfma4_bcast(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, kAbid, 0);
+}
+
+__global__ void mfma4_layout_probe_kernel(float* __restrict__ out) {   // [16][4][64]
+  const int l = threadIdx.x;
+  const float a = (float)(1000 * (l >> 2) + (l & 3) + 1);
+  const float b = (float)(l + 1);
+#define DDD_P4(ABID)                                                        \
+  {                                                                         \
+    f32x4 acc = {0.5f, 0.5f, 0.5f, 0.5f};                                   \
+    acc = mfma4_bcast<ABID>(a, b, acc);                                     \
+    for (int r = 0; r < 4; ++r) out[(ABID * 4 + r) * 64 + l] = acc[r];      \
+  }
+  DDD_P4(0) DDD_P4(1) DDD_P4(2) DDD_P4(3) DDD_P4(4) DDD_P4(5) DDD_P4(6) DDD_P4(7)
+  DDD_P4(8) DDD_P4(9) DDD_P4(10) DDD_P4(11) DDD_P4(12) DDD_P4(13) DDD_P4(14) DDD_P4(15)
+#undef DDD_P4
+}
+
 // Debug: record the hardware placement of each single-wave workgroup
 // (HW_REG_HW_ID and XCC_ID) under the same LDS footprint as the 64-row kernel.
 __global__ __launch_bounds__(64) void hwid_probe_kernel(unsigned* __restrict__ out, int spin) {
@@ -207,6 +233,31 @@ __global__ __launch_bounds__(64) void hwid_probe_kernel(unsigned* __restrict__ o
 // Debug: matrix-pipe rate probe.  Each wave issues `iters` x 8 MFMAs in
 // `chains` (1, 2 or 4) independent accumulator chains and reports s_memtime
 // ticks, so ticks per MFMA can be compared with the nominal 64 / 32 cycles.
+template <int kChains>
+__global__ __launch_bounds__(64) void mfma4_rate_probe_kernel(unsigned long long* out,
+                                                               int iters, float seed) {
+  f32x4 acc[4];
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) acc[c][r] = seed * (float)(c + r);
+  const float x = seed + threadIdx.x, y = seed * 0.5f - threadIdx.x;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const int c = k % kChains;
+      if ((k / kChains) & 1) acc[c] = mfma4_bcast<5>(x, y, acc[c]);
+      else acc[c] = mfma4_bcast<10>(x, y, acc[c]);
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float sink = 0.0f;
+  for (int c = 0; c < 4; ++c) sink += acc[c][0] + acc[c][3];
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 2 + 0] = t1 - t0;
+    out[blockIdx.x * 2 + 1] = (unsigned long long)__float_as_uint(sink);
+  }
+}
+
 template <int kChains, bool k32>
 __global__ __launch_bounds__(64) void mfma_rate_probe_kernel(unsigned long long* out,
                                                               int iters, float seed) {

@@ -20,27 +20,26 @@ def test_measured_traffic_lookup():
   assert table['entries'], 'PMC table is empty'
   for entry in table['entries']:
     m = entry['match']
-    got = bench.measured_traffic(m['equation'], m['num_points'], m['batch_per_gpu'],
-                                 m['launch_mode'], m['fixed'])
-    assert got == entry['traffic_bytes_per_launch']
+    got, source = bench.measured_traffic(m['equation'], m['num_points'], m['batch_per_gpu'],
+                                         m['launch_mode'], m['fixed'])
+    assert got == entry['traffic_bytes_per_launch'] and source.startswith('profiles/')
     # FETCH_SIZE (with the gfx950 correction) + WRITE_SIZE, in bytes
     want = 1024 * (entry['fetch_correction'] * entry['fetch_size_kb'] + entry['write_size_kb'])
     assert abs(got - want) < 1.0
   # the headline configuration is in the table; unprofiled ones report null
-  assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1024, 'persistent', False)
-  assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1000, 'persistent', False) is None
+  assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1024, 'persistent', False)[0]
+  assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1000, 'persistent',
+                                False) == (None, None)
 
 
 def test_bench_defaults_match_baseline_config():
-  """BASELINE.json configs[1]: Burgers N=64, batch 1024, 1000 steps."""
-  import sys
+  """Primary: BASELINE.json north_star target (Burgers N=64, batch 4096, 1 GPU);
+  secondary in the same run: configs[1] (batch 1024), 1000 steps."""
   bench = _bench()
-  argv, sys.argv = sys.argv, ['bench.py']
-  try:
-    args = bench.parse_args()
-  finally:
-    sys.argv = argv
+  args = bench.parse_args([])
   assert (args.gpus, args.steps, args.batch, args.num_points, args.equation) == (
-      1, 1000, 1024, 64, 'burgers')
+      1, 1000, 4096, 64, 'burgers')
+  assert args.secondary_batch == 1024
+  assert args.preheat_ms >= 200.0 and args.min_timed_ms >= 20.0
   assert args.scheme == 'midpoint' and args.launch_mode == 'persistent'
   assert bench.PEAK_FP32_TFLOPS == 157.3 and bench.PEAK_HBM_GBPS == 8000.0
