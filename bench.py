@@ -88,6 +88,9 @@ def parse_args(argv=None):
                   help='run the timed kernel this long before --warmup (0 disables)')
   ap.add_argument('--min-timed-ms', type=float, default=40.0,
                   help='repeat the K-step job until the timed region lasts this long')
+  ap.add_argument('--debug-option', action='append', default=[], metavar='NAME=VALUE',
+                  help='library A/B switch (ddd_debug_set_option), e.g. no_spec=1; '
+                       'logged to stderr, never set in a headline run')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
   return ap.parse_args(argv)
@@ -174,32 +177,54 @@ def cpu_baseline(model, forcing, y0, scheme, dt, budget_s):
 
 
 class ClockSampler(object):
-  """Samples the shader clock and socket power of one GPU from sysfs (amdgpu
-  hwmon: freq1_input [Hz], power1_average / power1_input [uW]) in a background
-  thread while the kernel runs: evidence for the sustained-clock figure in
-  DESIGN.md.  Silent (returns None) where the files do not exist."""
+  """Samples the shader clock and socket power of the GPU this rank runs on
+  from sysfs (amdgpu hwmon: freq1_input [Hz], power1_average / power1_input
+  [uW]) in a background thread while the kernel runs: evidence for the
+  sustained-clock figure in DESIGN.md.  The card is found by the PCI address
+  torch reports for the device; when that is unavailable every amdgpu card is
+  sampled and the busiest one (highest mean clock in the window) is reported.
+  Silent (returns None) where the files do not exist."""
 
-  def __init__(self, device_index=0, period_s=0.005):
+  def __init__(self, device_index=0, period_s=0.004):
     self.period = period_s
     self.samples = []
     self._stop = threading.Event()
     self._thread = None
-    self.freq_path, self.power_path = self._find(device_index)
+    self.cards = self._find(device_index)   # [(freq_path, power_path)]
 
   @staticmethod
-  def _find(device_index):
-    cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'),
-                   key=lambda p: int(p.split('/card')[1].split('/')[0]))
-    cards = [c for c in cards if os.path.exists(os.path.join(c, 'freq1_input'))]
-    if device_index >= len(cards):
-      return None, None
-    base = cards[device_index]
-    power = None
-    for name in ('power1_average', 'power1_input'):
-      if os.path.exists(os.path.join(base, name)):
-        power = os.path.join(base, name)
-        break
-    return os.path.join(base, 'freq1_input'), power
+  def _pci_address(device_index):
+    try:
+      import torch
+      props = torch.cuda.get_device_properties(device_index)
+      return '{:04x}:{:02x}:{:02x}.0'.format(props.pci_domain_id, props.pci_bus_id,
+                                             props.pci_device_id)
+    except Exception:   # attribute missing on this torch build
+      return None
+
+  @classmethod
+  def _find(cls, device_index):
+    def hwmon_of(device_dir):
+      out = []
+      for base in sorted(glob.glob(os.path.join(device_dir, 'hwmon', 'hwmon*'))):
+        if not os.path.exists(os.path.join(base, 'freq1_input')):
+          continue
+        power = None
+        for name in ('power1_average', 'power1_input'):
+          if os.path.exists(os.path.join(base, name)):
+            power = os.path.join(base, name)
+            break
+        out.append((os.path.join(base, 'freq1_input'), power))
+      return out
+    address = cls._pci_address(device_index)
+    if address is not None:
+      cards = hwmon_of(os.path.join('/sys/bus/pci/devices', address))
+      if cards:
+        return cards[:1]
+    cards = []
+    for dev in sorted(glob.glob('/sys/class/drm/card[0-9]*/device')):
+      cards.extend(hwmon_of(dev))
+    return cards
 
   @staticmethod
   def _read(path):
@@ -211,13 +236,15 @@ class ClockSampler(object):
 
   def _loop(self):
     while not self._stop.is_set():
-      freq = self._read(self.freq_path)
-      power = self._read(self.power_path) if self.power_path else None
-      self.samples.append((time.perf_counter(), freq, power))
+      now = time.perf_counter()
+      for index, (freq_path, power_path) in enumerate(self.cards):
+        freq = self._read(freq_path)
+        power = self._read(power_path) if power_path else None
+        self.samples.append((now, index, freq, power))
       time.sleep(self.period)
 
   def start(self):
-    if self.freq_path is None:
+    if not self.cards:
       return self
     self._thread = threading.Thread(target=self._loop, daemon=True)
     self._thread.start()
@@ -228,18 +255,23 @@ class ClockSampler(object):
       return None
     self._stop.set()
     self._thread.join()
-    rows = [s for s in self.samples
-            if (t_begin is None or s[0] >= t_begin) and (t_end is None or s[0] <= t_end)]
-    freqs = [s[1] / 1e6 for s in rows if s[1]]
-    powers = [s[2] / 1e6 for s in rows if s[2]]
-    if not freqs:
-      return None
-    out = {'source': self.freq_path, 'samples': len(freqs),
-           'sclk_mhz_mean': sum(freqs) / len(freqs), 'sclk_mhz_min': min(freqs),
-           'sclk_mhz_max': max(freqs)}
-    if powers:
-      out.update(power_w_mean=sum(powers) / len(powers), power_w_max=max(powers))
-    return out
+    best = None
+    for index, (freq_path, _) in enumerate(self.cards):
+      rows = [s for s in self.samples if s[1] == index
+              and (t_begin is None or s[0] >= t_begin) and (t_end is None or s[0] <= t_end)]
+      freqs = [s[2] / 1e6 for s in rows if s[2]]
+      powers = [s[3] / 1e6 for s in rows if s[3]]
+      if not freqs:
+        continue
+      out = {'source': freq_path, 'samples': len(freqs),
+             'matched_by': 'pci address' if len(self.cards) == 1 else 'busiest card',
+             'sclk_mhz_mean': sum(freqs) / len(freqs), 'sclk_mhz_min': min(freqs),
+             'sclk_mhz_max': max(freqs)}
+      if powers:
+        out.update(power_w_mean=sum(powers) / len(powers), power_w_max=max(powers))
+      if best is None or out['sclk_mhz_mean'] > best['sclk_mhz_mean']:
+        best = out
+    return best
 
 
 def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
@@ -404,6 +436,9 @@ def main():
 
   import ddd1d_amd
   lib = ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
+  for item in args.debug_option:
+    name, _, value = item.partition('=')
+    ddd1d_amd._lib.debug_set_option(name, int(value or '1'))
   stages = lib.ddd_scheme_stages(ddd1d_amd._lib.SCHEMES[args.scheme])
   batch = args.batch
   eq, model, forcing, y0_host = build_workload(args, rank, batch)
@@ -458,6 +493,7 @@ def main():
             'fma_per_point_eval': model.fma_per_point,
             'parallelism': 'ensemble-shard x{}'.format(world),
             'finite': m['finite'],
+            'debug_options': args.debug_option,
             'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,
             'timed_wall_ms': m['wall'] * 1e3,
         },

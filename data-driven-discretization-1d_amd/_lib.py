@@ -300,6 +300,16 @@ def apply_space_derivatives(equation_id: int, derivatives, inputs, eta: float, d
   return out
 
 
+def debug_set_option(name: str, value: int):
+  """Profiling / A-B switches of the library (capi.hip: ddd_debug_set_option);
+  every change is logged to stderr by the library.  Not a product API."""
+  lib = load_library()
+  fn = lib.ddd_debug_set_option
+  fn.restype = ctypes.c_int
+  fn.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+  check(fn(name.encode('utf-8'), int(value)))
+
+
 def selftest_mfma_layout():
   lib = load_library()
   require_gpu()

@@ -443,27 +443,48 @@ def _len_prefixed(payload: bytes) -> bytes:
 # ---------------------------------------------------------------------------
 # the reference's variable naming
 # ---------------------------------------------------------------------------
-def conv_variable_names(num_layers: int) -> List[Tuple[str, str]]:
-  """(kernel, bias) variable names in graph order: tf.layers.conv1d inside
-  tf.variable_scope('predict_coefficients') uniquifies as conv1d, conv1d_1, ..."""
+def conv_variable_names(num_layers: int,
+                        model_target: str = 'coefficients') -> List[Tuple[str, str]]:
+  """(kernel, bias) variable names in graph order.
+
+  tf.layers.conv1d uniquifies as conv1d, conv1d_1, ...  Only
+  ``model.predict_coefficients`` opens ``tf.variable_scope('predict_coefficients')``
+  (model.py:442); the heads for model_target in {space_derivatives,
+  time_derivative, flux} are built by ``_multilayer_conv1d`` with no scope
+  (model.py:551-569), so their variables are plain ``conv1d/kernel`` etc."""
+  prefix = 'predict_coefficients/' if model_target == 'coefficients' else ''
   names = []
   for layer in range(num_layers):
-    scope = 'predict_coefficients/conv1d' + ('_%d' % layer if layer else '')
+    scope = prefix + 'conv1d' + ('_%d' % layer if layer else '')
     names.append((scope + '/kernel', scope + '/bias'))
   return names
 
 
-def load_conv_weights(checkpoint_dir: str, num_layers: int):
+CONSTANT_COEFFICIENTS_NAME = 'predict_coefficients/coefficients'   # model.py:496-499
+
+
+def load_conv_weights(checkpoint_dir: str, num_layers: int,
+                      model_target: str = 'coefficients'):
   """(kernels [K, Cin, Cout], biases [Cout]) float32 lists from model.ckpt."""
   tensors = read_checkpoint(os.path.join(checkpoint_dir, CHECKPOINT_PREFIX))
   kernels, biases = [], []
-  for kernel_name, bias_name in conv_variable_names(num_layers):
+  for kernel_name, bias_name in conv_variable_names(num_layers, model_target):
     if kernel_name not in tensors or bias_name not in tensors:
       raise KeyError('checkpoint has no variable {!r}; found {}'.format(
           kernel_name, sorted(k for k in tensors if 'Adam' not in k)))
     kernels.append(tensors[kernel_name].astype(np.float32))
     biases.append(tensors[bias_name].astype(np.float32))
   return kernels, biases
+
+
+def load_constant_coefficients(checkpoint_dir: str) -> np.ndarray:
+  """The learned constant vector of a ``num_layers = 0`` model
+  (``predict_coefficients/coefficients``, model.py:496-499)."""
+  tensors = read_checkpoint(os.path.join(checkpoint_dir, CHECKPOINT_PREFIX))
+  if CONSTANT_COEFFICIENTS_NAME not in tensors:
+    raise KeyError('checkpoint has no variable {!r}; found {}'.format(
+        CONSTANT_COEFFICIENTS_NAME, sorted(k for k in tensors if 'Adam' not in k)))
+  return tensors[CONSTANT_COEFFICIENTS_NAME].astype(np.float32)
 
 
 def has_tf_checkpoint(checkpoint_dir: str) -> bool:

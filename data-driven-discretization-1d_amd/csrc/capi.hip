@@ -25,6 +25,22 @@ namespace {
 
 thread_local std::string g_error;
 
+// Profiling / A-B switches.  They are set ONLY through ddd_debug_set_option
+// (an explicit call that logs to stderr), never read from the environment: a
+// stray variable must not be able to change the numerics path, skip kernel
+// phases or hand the kernel a raw address.
+struct DebugOptions {
+  int no_fold = 0;       // keep the projection out of the output layer (D <= 2 models)
+  int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
+  int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
+  int no_pair = 0;       // free-running one-wave groups instead of token-paired ones
+  int prio_split = 0;    // A/B: static wave priorities
+  int stagger = 0;       // A/B: initial s_sleep of odd wave slots
+  int ablate = 0;        // skips kernel phases: WRONG RESULTS (run-time-parameterised kernels)
+  unsigned long long trace_ptr = 0;   // device buffer for s_memtime phase stamps
+};
+DebugOptions g_debug;
+
 int fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
@@ -146,7 +162,8 @@ struct ddd_model {
   float* d_bias = nullptr;
   float* d_w_input = nullptr;
   float* d_w_hidden = nullptr;
-  float* d_w_final = nullptr;
+  float* d_w_final4 = nullptr;
+  float* d_w_final4_pad = nullptr;
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
   float* d_trig = nullptr;
@@ -270,8 +287,7 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     const float* w = w_nat;
     const float* b = b_nat;
     m->dp.folded = 0;
-    const char* nofold = std::getenv("DDD_NO_FOLD");
-    if (dp.D <= 2 && !(nofold != nullptr && nofold[0] == '1')) {
+    if (dp.D <= 2 && !g_debug.no_fold) {
       // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
       // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
       // (accumulated in double, rounded once to float32), same for the bias.
@@ -302,21 +318,41 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
       b = bf.data();
       m->dp.folded = 1;
     }
-    std::vector<float> packed((size_t)ddd::mfma::kFinSteps * 64, 0.0f);
-    for (int s = 0; s < 40; ++s) {
-      const int tap = s / 8, jj = s % 8;
-      for (int lane = 0; lane < 64; ++lane) {
-        const int cin = 8 * (lane >> 4) + jj, cout = lane & 15;
-        packed[s * 64 + lane] = cout < cout_n ? w[(tap * 32 + cin) * cout_n + cout] : 0.0f;
-      }
-    }
-    for (int lane = 0; lane < 64; ++lane) {
-      const int cout = lane & 15;
-      packed[40 * 64 + lane] = ((lane >> 4) == 0 && cout < cout_n) ? b[cout] : 0.0f;
-    }
-    int rc = upload(packed, &m->d_w_final);
+    // Packing for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4): channels
+    // grouped by four; instruction q = k * groups + grp reads lanes
+    // 4 (q % 16) .. + 3 of weight register q / 16, lane 4 abid + r carrying
+    // channel 4 grp + r; k = (tap, cin) in natural order, k = 160: bias.
+    //   w_final4    : live channels renumbered contiguously (folded: G d + g),
+    //                 ceil(n / 4) groups -- the per-equation specialised kernels
+    //   w_final4_pad: the 16 channels as they are (folded: 8 d + g), 4 groups --
+    //                 the run-time-parameterised kernels
+    const int n_ch = m->dp.folded ? dp.D * dp.G : dp.C_out;
+    auto pack4 = [&](int groups, bool renumber) {
+      std::vector<float> packed4((size_t)ddd::mfma::fin4_regs(4) * 64, 0.0f);
+      for (int k = 0; k < ddd::mfma::kFin4K; ++k)
+        for (int grp = 0; grp < groups; ++grp) {
+          const int q = k * groups + grp;
+          for (int r = 0; r < 4; ++r) {
+            const int ch = 4 * grp + r;
+            int src = ch;
+            if (renumber) {
+              if (ch >= n_ch) continue;
+              src = m->dp.folded ? 8 * (ch / dp.G) + ch % dp.G : ch;
+            }
+            if (src >= cout_n) continue;
+            packed4[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
+                k < 160 ? w[(size_t)k * cout_n + src] : b[src];
+          }
+        }
+      return packed4;
+    };
+    m->dp.fin4_groups = (n_ch + 3) / 4;
+    int rc = upload(pack4(m->dp.fin4_groups, true), &m->d_w_final4);
     if (rc) return rc;
-    m->dp.w_final = m->d_w_final;
+    m->dp.w_final4 = m->d_w_final4;
+    rc = upload(pack4(4, false), &m->d_w_final4_pad);
+    if (rc) return rc;
+    m->dp.w_final4_pad = m->d_w_final4_pad;
   }
   return DDD_OK;
 }
@@ -430,8 +466,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
 // width, projection folded when D <= 2) on a non-Godunov equation.
 int spec_equation(const ddd_model* m) {
   const ddd::DevParams& dp = m->dp;
-  const char* off = std::getenv("DDD_NO_SPEC");
-  if (off != nullptr && off[0] == '1') return -1;
+  if (g_debug.no_spec) return -1;
   if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
   if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
   if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
@@ -453,8 +488,7 @@ bool aligned16(const void* ptr) {
 bool use_stream_kernel(const ddd_model* m, const ddd::SubstepArgs& a) {
   if (!ddd::stream::supports(m->dp) || m->explicit_kernel) return false;
   if (a.derivs_out != nullptr || a.coeffs_out != nullptr) return false;
-  const char* off = std::getenv("DDD_NO_STREAM");
-  if (off != nullptr && off[0] == '1') return false;
+  if (g_debug.no_stream) return false;
   return aligned16(a.y_in) && aligned16(a.y_base) && aligned16(a.y_out) &&
          aligned16(a.acc_in) && aligned16(a.acc_out);
 }
@@ -574,18 +608,11 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
   m->last_batch = a.batch;
   m->last_launch_streamed = false;
-  {
-    // profiling knobs (see profiles/r1_ablation.txt); all off by default
-    const char* env = std::getenv("DDD_PRIO_SPLIT");
-    a.prio_split = env != nullptr ? std::atoi(env) : 0;
-    const char* stg = std::getenv("DDD_STAGGER");
-    a.stagger = stg != nullptr ? std::atoi(stg) : 0;
-    const char* trc = std::getenv("DDD_TRACE_PTR");   // device buffer address
-    a.trace = trc != nullptr ? reinterpret_cast<unsigned long long*>(std::strtoull(trc, nullptr, 0))
-                             : nullptr;
-    const char* abl = std::getenv("DDD_ABLATE");      // skips phases: WRONG RESULTS
-    a.ablate = abl != nullptr ? std::atoi(abl) : 0;
-  }
+  // profiling knobs (ddd_debug_set_option; see profiles/r1_ablation.txt); all off by default
+  a.prio_split = g_debug.prio_split;
+  a.stagger = g_debug.stagger;
+  a.trace = reinterpret_cast<unsigned long long*>(g_debug.trace_ptr);
+  a.ablate = g_debug.ablate;
   if (m->kernel == DDD_KERNEL_MFMA) {
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
@@ -862,7 +889,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_final); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  free_dev(m->d_w_final4); free_dev(m->d_w_final4_pad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
@@ -1279,6 +1306,26 @@ int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0;
 // ("stream_fixed", "mfma", "generic"; "" before the first launch).  Tests only.
 const char* ddd_debug_last_substep_kernel(const ddd_model* m) {
   return m != nullptr ? m->last_substep_kernel : "";
+}
+
+// Profiling / A-B switches (not part of the product API; every change is
+// logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
+// no_stream, no_pair, prio_split, stagger, ablate, trace_ptr.
+int ddd_debug_set_option(const char* name, long long value) {
+  if (name == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "name is NULL");
+  const std::string key(name);
+  if (key == "no_fold") g_debug.no_fold = (int)value;
+  else if (key == "no_spec") g_debug.no_spec = (int)value;
+  else if (key == "no_stream") g_debug.no_stream = (int)value;
+  else if (key == "no_pair") g_debug.no_pair = (int)value;
+  else if (key == "prio_split") g_debug.prio_split = (int)value;
+  else if (key == "stagger") g_debug.stagger = (int)value;
+  else if (key == "ablate") g_debug.ablate = (int)value;
+  else if (key == "trace_ptr") g_debug.trace_ptr = (unsigned long long)value;
+  else return fail(DDD_ERR_INVALID_ARGUMENT, "unknown debug option '%s'", name);
+  fprintf(stderr, "libddd1d: debug option %s = %lld%s\n", name, value,
+          key == "ablate" && value != 0 ? " (kernel phases skipped: results are WRONG)" : "");
+  return DDD_OK;
 }
 
 int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {

@@ -53,7 +53,10 @@ struct DevParams {
   int folded;
   const float* w_input;    // MFMA-packed input layer, 3 x 64
   const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
-  const float* w_final;    // MFMA-packed output layer, 41 x 64
+  // output layer packed for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4), 41 x 64:
+  const float* w_final4;      // live channels renumbered contiguously, ceil(channels / 4) groups
+  const float* w_final4_pad;  // 16 channels in natural / 8 d + g numbering, 4 groups
+  int fin4_groups;            // groups of w_final4
   // per-sample forcing
   int forced, P, n_k, forcing_batch;
   const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)

@@ -13,7 +13,8 @@
 //       - input layer   1 -> 32, K=5 : v_mfma_f32_32x32x2_f32, 3 steps (5 taps + bias)
 //       - hidden layers 32 -> 32, K=5: v_mfma_f32_32x32x2_f32, 80 steps + 1 bias step;
 //         the layer's 160x32 weight panel lives in 81 VGPRs per lane
-//       - output layer  32 -> C_out<=16: v_mfma_f32_16x16x4_f32, 40 steps + 1 bias step
+//       - output layer  32 -> C_out<=16: v_mfma_f32_4x4x1_16b_f32 with the weight block
+//         broadcast, 161 steps x ceil(C / 4) channel groups, lane == row (final_layer4)
 //   * the VALU does what is left with lane == row: projection onto the
 //     accuracy-constrained stencils, stencil apply, equation of motion, forcing
 //     and the Runge-Kutta update;
@@ -26,6 +27,8 @@
 // f32-input MFMA is bit-for-bit an fmaf chain in k order, so the arithmetic is
 // IEEE float32 like the reference's TF graph; only the summation order differs.
 #pragma once
+#include <utility>
+
 #include "dev_params.h"
 
 namespace ddd {
@@ -36,9 +39,7 @@ constexpr int kF = 32;           // hidden channels
 constexpr int kKW = 5;           // conv taps
 constexpr int kInSteps = 3;      // (5 taps + bias) / 2
 constexpr int kHidSteps = 81;    // 5*32/2 MFMA steps + 1 bias step
-constexpr int kFinSteps = 41;    // 5*32/4 MFMA steps + 1 bias step
-constexpr int kFinPrefetch = 0;  // output-layer weight registers fetched before the hidden layers
-                                 // (A/B on MI355X: 8 made the output layer ~1000 cycles slower)
+constexpr int kFin4K = kKW * kF + 1;   // output layer on 4x4x1 MFMAs: 160 reduction steps + bias
 constexpr int kTrigMax = 12;     // 2 * (distinct wavenumbers) kept per lane
 constexpr int kTabRows = 4 + 16; // bias8 rows + one null-space row per output channel
 
@@ -88,6 +89,88 @@ __host__ __device__ constexpr bool spec_flux_form(int eq) {
   return eq == EQ_BURGERS_CONS || eq == EQ_KDV_CONS || eq == EQ_KS_CONS;
 }
 __host__ __device__ constexpr int spec_stencil(int eq) { return spec_flux_form(eq) ? 6 : 7; }
+// Output channels of the specialised kernels' last layer, in groups of four
+// (final_layer4): D <= 2: the folded layer emits the D x G stencil coefficients
+// (12 or 14 channels); D = 3 (KS): the 5 + 4 + 2 null-space coordinates.
+__host__ __device__ constexpr int spec_fin_channels(int eq) {
+  return spec_derivs(eq) <= 2 ? spec_derivs(eq) * spec_stencil(eq) : 11;
+}
+__host__ __device__ constexpr int spec_fin_groups(int eq) { return (spec_fin_channels(eq) + 3) / 4; }
+__host__ __device__ constexpr int fin4_regs(int groups) { return (kFin4K * groups + 15) / 16; }
+
+// ---------------------------------------------------------------------------
+// Token-paired wavefronts (kPair).  Two wavefronts share each SIMD; both run
+// the same program, and left alone they fall into lock step -- both in their
+// MFMA phases (sharing the pipe), then both in their VALU / LDS gaps with the
+// matrix pipe idle: measured, a co-resident pair costs 2 x MFMA time + the
+// gaps, hardly better than running the two one after the other.  A paired
+// workgroup holds EIGHT independent one-wave groups (one sample each at
+// N = 64) = two per SIMD of its CU; the two that landed on the same SIMD
+// (HW_ID.simd_id) pass a token through one LDS word and run their MFMA blocks
+// strictly alternately:
+//     A.hidden[0:10)  B.output  A.hidden[10:20)  B.hidden[0:10)  A.output  B.hidden[10:20) ...
+// so that every VALU / LDS gap of one wavefront (layer boundary, epilogue,
+// Runge-Kutta update, next input layer) lies under an MFMA block of the other.
+// The groups share nothing else: a "group" below is one wavefront with its own
+// Shared block; group_sync is a wavefront-local fence.
+// ---------------------------------------------------------------------------
+constexpr int kPairWaves = 8;       // one-wave groups per paired workgroup
+constexpr int kTokenFree = 1 << 30; // turn value that releases the partner for good
+
+template <bool kPair>
+__device__ __forceinline__ int group_tid() {
+  return kPair ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+}
+template <bool kPair>
+__device__ __forceinline__ int group_block() {
+  return kPair ? (int)(blockIdx.x * kPairWaves + (threadIdx.x >> 6)) : (int)blockIdx.x;
+}
+template <bool kPair>
+__device__ __forceinline__ void group_sync() {
+  if (kPair) {
+    // one wavefront: its LDS operations execute in order, only the compiler
+    // must not move accesses across
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
+struct PairToken {
+  int* turn;   // LDS word of this SIMD's pair; nullptr: free-running
+  int mine;    // turn value at which this wavefront runs its next MFMA block
+
+  __device__ __forceinline__ bool paired() const {
+    return __builtin_amdgcn_readfirstlane((int)(turn != nullptr)) != 0;
+  }
+  // Spin (s_sleep between LDS polls) until it is this wavefront's turn.  A
+  // bounded wait: a partner that never shows up (it cannot, but a hang would
+  // take the GPU with it) dissolves the pair instead.
+  __device__ __forceinline__ void acquire() {
+    if (!paired()) return;
+    __builtin_amdgcn_sched_barrier(0);
+    int spins = 0;
+    while (__builtin_amdgcn_readfirstlane(*(volatile int*)turn) < mine) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 16)) { finish(); break; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void release() {
+    if (!paired()) return;
+    __builtin_amdgcn_sched_barrier(0);
+    if ((threadIdx.x & 63) == 0) atomicMax(turn, mine + 1);   // never lowers kTokenFree
+    mine += 2;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __device__ __forceinline__ void finish() {
+    if (!paired()) return;
+    if ((threadIdx.x & 63) == 0) atomicMax(turn, kTokenFree);
+    turn = nullptr;
+  }
+};
 
 struct Lane {
   int row;       // row inside the workgroup this lane owns in VALU phases
@@ -110,7 +193,7 @@ __device__ __forceinline__ int row_sample(int row, float inv_n) {
 }
 
 template <int kRows, int kWR>
-__device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid) {
+__device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid, int block) {
   Lane ln;
   ln.wave = tid >> 6;
   ln.lane = tid & 63;
@@ -135,7 +218,7 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, int batch, int tid
     // every LDS index stays in range; results are never stored.
     ln.sl = 0; ln.base = 0; ln.pos = 0;
   }
-  const long sample = (long)blockIdx.x * spg + ln.sl;
+  const long sample = (long)block * spg + ln.sl;
   ln.valid = (ln.row < ln.rows_used) && (sample < batch);
   ln.active = ln.valid && ln.owner;
   ln.gidx = sample * p.N + ln.pos;
@@ -199,7 +282,6 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 }
 
 #define DDD_MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
-#define DDD_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
   if (act == ACT_RELU) {
@@ -282,12 +364,16 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
 //   reduction index    : step s = 16 tap + jj, half = l >> 5  <->  (tap, cin = 16 half + jj)
 // The 16 floats a lane needs per tap are four ds_read_b128; the read of group
 // g + 1 is issued before the four MFMAs of group g (software prefetch).
-template <int kWR>
+// `mid` runs between operand groups 9 and 10 (paired kernels: token hand-over).
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+
+template <int kWR, typename Mid = NoMid>
 __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
-                                             const int (&rows)[2][kKW], int act) {
+                                             const int (&rows)[2][kKW], int act,
+                                             Mid mid = Mid()) {
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -331,6 +417,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
     // schedule: read group g+1 of every tile, then the MFMAs of group g
     __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);       // DS reads
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kT, 0);   // MFMAs
+    if (g == 9) mid();
   }
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
@@ -343,94 +430,91 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   }
 }
 
-// Output layer (32 -> C_out <= 16, linear) for this wave's 16-row tiles (4 or 2).
-//   A: lane l supplies W[out = l & 15][k = 4 s + (l >> 4)]
-//   B: lane l supplies h[k = 4 s + (l >> 4)][position = l & 15]
-//   step s = 8 tap + jj, quarter = l >> 4  <->  (tap, cin = 8 quarter + jj)
-//   D: lane l holds position l & 15, out-channel 4 (l >> 4) + r.
-// Its 41 weight registers are loaded by the caller BEFORE the hidden layers run
-// (the L2 latency hides behind their MFMAs) and die with this function.
-__device__ __forceinline__ void load_final(const DevParams& p, int lane,
-                                           float (&w)[kFinSteps]) {
-  const float* src = p.w_final + lane;
-#pragma unroll
-  for (int s = 0; s < kFinSteps; ++s) w[s] = src[s * 64];
+// Output layer (32 -> C_out <= 16, linear) on v_mfma_f32_4x4x1_16b_f32.  A
+// 16x16x4 formulation pads the 11-14 live output channels to 16 and leaves the
+// result in a (position, channel-quad) layout that has to travel through LDS to
+// reach the lane == row epilogue (round 1: 5248 pipe cycles + a store, a
+// barrier and a read-back).  The 16-block 4x4x1 form with the A block broadcast
+// (cbsz = 4, abid = b: lanes 4 b .. 4 b + 3 of the A register feed ALL blocks)
+// computes, per instruction, four output channels x one reduction step for 64
+// positions with B = one value per lane:
+//   D[r] of lane l += W[k][4 grp + r] * h[k][row of lane l]
+// so (a) only ceil(C / 4) channel groups are issued (C = 12: 3 groups, 483
+// instructions x 8 cycles = 3864 pipe cycles instead of 5248), (b) one weight
+// register holds 16 (k, group) slots -- 31 registers for 483 instructions --
+// and (c) every lane ends up with its OWN row's channels: no LDS round trip.
+//   instruction q = (((tap * 8 + c4) * 4 + e) * NG + grp), k = tap * 32 + 4 c4 + e,
+//   weight register q / 16, abid q % 16 (capi.hip: pack_final4); q = 160 NG + grp:
+//   bias row against B = 1.
+// B operands: the lane's own five tap rows, 8 x ds_read_b128 each (row stride
+// 144 B keeps 16 consecutive rows on distinct 16-byte bank slots), prefetched
+// two operand groups (24-32 MFMAs) ahead.
+template <int kAbid>
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, kAbid, 0);
 }
 
-// kByteOffsets: `rows` already holds the LDS byte offsets of the operand rows
-// (kept resident by the specialised one-wave kernels) instead of row numbers.
-template <int kWR, bool kByteOffsets>
-__device__ __forceinline__ void final_layer(const DevParams& p, const Lane& ln,
-                                            const float* __restrict__ in,
-                                            float* __restrict__ out,
-                                            const float (&wf)[kFinSteps],
-                                            const int (&rows)[4][kKW]) {
-  constexpr int kT = kWR / 16;   // 16-row tiles of this wave
-  const int j = ln.lane & 15;
-  const int quarter = ln.lane >> 4;
-  // Ten operand groups (tap, half-of-the-8-channels); each group is one
-  // ds_read_b128 per tile feeding four MFMAs per tile.  The tiles'
-  // accumulators are independent chains issued round-robin (a dependent
-  // 16x16x4 needs 40 cycles, the pipe takes one every 32), and the reads of
-  // group g + 1 are issued before the MFMAs of group g.
-  int rowo[kT][kKW];   // 32-bit byte offsets, see hidden_layer
+template <int NG, int Q0, int... J>
+__device__ __forceinline__ void fin4_mfmas(const float (&w)[fin4_regs(NG)], const f32x4& b,
+                                           f32x4 (&acc)[NG], std::integer_sequence<int, J...>) {
+  ((acc[J % NG] = mfma4<(Q0 + J) % 16>(w[(Q0 + J) / 16], b[J / NG], acc[J % NG])), ...);
+}
+
+template <int NG>
+__device__ __forceinline__ void load_final4(const DevParams& p, int lane,
+                                            float (&w)[fin4_regs(NG)]) {
+  const float* src = p.w_final4 + lane;
 #pragma unroll
-  for (int t = 0; t < kT; ++t)
+  for (int s = 0; s < fin4_regs(NG); ++s) w[s] = src[s * 64];
+}
+
+constexpr int kFin4Ahead = 2;   // operand groups in flight ahead of the MFMAs
+
+template <int NG, int OG>
+__device__ __forceinline__ void fin4_step(const char* __restrict__ in, const int (&off)[kKW],
+                                          const float (&w)[fin4_regs(NG)],
+                                          f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG]) {
+  constexpr int kNext = OG + kFin4Ahead;
+  if constexpr (kNext < 40)
+    buf[kNext % (kFin4Ahead + 1)] =
+        *reinterpret_cast<const f32x4*>(in + off[kNext / 8] + 16 * (kNext % 8));
+  fin4_mfmas<NG, OG * 4 * NG>(w, buf[OG % (kFin4Ahead + 1)], acc,
+                              std::make_integer_sequence<int, 4 * NG>{});
+  if constexpr (kNext < 40) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+  __builtin_amdgcn_sched_group_barrier(0x008, 4 * NG, 0);                        // MFMAs
+}
+
+template <int NG, int... OG>
+__device__ __forceinline__ void fin4_run(const char* __restrict__ in, const int (&off)[kKW],
+                                         const float (&w)[fin4_regs(NG)],
+                                         f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG],
+                                         std::integer_sequence<int, OG...>) {
+  (fin4_step<NG, OG>(in, off, w, buf, acc), ...);
+}
+
+// `off`: LDS byte offsets (row * kHS * 4) of the lane's five tap rows.
+template <int NG>
+__device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
+                                             const float (&w)[fin4_regs(NG)],
+                                             const int (&off)[kKW], f32x4 (&acc)[NG]) {
+  const char* __restrict__ in = reinterpret_cast<const char*>(in_f);
+  f32x4 buf[kFin4Ahead + 1];
 #pragma unroll
-    for (int tap = 0; tap < kKW; ++tap)
-      rowo[t][tap] = kByteOffsets ? rows[t][tap]
-                                  : (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) +
-                                        32 * quarter;   // bytes
-  const auto operand = [&](int t, int tap, int q) {
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) + rowo[t][tap] + 16 * q);
-  };
-  f32x4 acc[kT];
-  float4 cur[kT], nxt[kT];
+  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-  for (int t = 0; t < kT; ++t) {
-    acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    cur[t] = operand(t, 0, 0);
-  }
-  __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
-#pragma unroll
-  for (int g = 0; g < 10; ++g) {
-    if (g + 1 < 10) {
-#pragma unroll
-      for (int t = 0; t < kT; ++t) nxt[t] = operand(t, (g + 1) >> 1, (g + 1) & 1);
-    }
-    const float* w = wf + 4 * g;
-#pragma unroll
-    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[0], cur[t].x, acc[t]);
-#pragma unroll
-    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[1], cur[t].y, acc[t]);
-#pragma unroll
-    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[2], cur[t].z, acc[t]);
-#pragma unroll
-    for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(w[3], cur[t].w, acc[t]);
-    if (g + 1 < 10) {
-#pragma unroll
-      for (int t = 0; t < kT; ++t) cur[t] = nxt[t];
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);       // DS reads (group g + 1)
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kT, 0);   // MFMAs (group g)
-  }
-  const float wb = wf[40];
-#pragma unroll
-  for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA16(wb, 1.0f, acc[t]);   // bias row
-#pragma unroll
-  for (int t = 0; t < kT; ++t) {
-    const int trow = ln.wave * kWR + t * 16 + j;
-    *reinterpret_cast<float4*>(out + trow * kHS + 4 * quarter) =
-        make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-  }
+  for (int og = 0; og < kFin4Ahead; ++og)
+    buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / 8] + 16 * (og % 8));
+  __builtin_amdgcn_sched_group_barrier(0x100, kFin4Ahead, 0);
+  fin4_run<NG>(in, off, w, buf, acc, std::make_integer_sequence<int, 40>{});
+  // bias row: k = 160 against a constant 1
+  fin4_mfmas<NG, 160 * NG>(w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc,
+                           std::make_integer_sequence<int, NG>{});
 }
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
-constexpr int kFinKeep = kFinSteps;   // output-layer weight registers kept for the whole launch (see eval_rhs)
-
 struct Resident {
-  float w_fin[kFinKeep];    // the first kFinKeep output-layer weights (specialised one-wave kernels)
-  int fin_off[4][kKW];      // LDS byte offsets of the output layer's operand rows (same kernels)
+  float w_fin4[fin4_regs(4)];   // output layer weights (specialised one-wave integrators)
+  int fin4_off[kKW];        // LDS byte offsets of this lane's five tap rows (same kernels)
   int pch_idx[kGMax];       // indices into Shared::u of this row's stencil patch (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
@@ -478,11 +562,11 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Re
   return acc;
 }
 
-template <int kRows, int kWR>
+template <int kRows, int kWR, bool kPair = false>
 __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
-  __syncthreads();
+  group_sync<kPair>();
   return forcing_phase2<kRows, kWR>(sm, res);
 }
 
@@ -493,13 +577,16 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace>
+// kPair: the group is one wavefront of a paired workgroup (see PairToken); `tok`
+// brackets its MFMA blocks.
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kPair = false>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
-                                          unsigned long long* trace = nullptr) {
-#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+                                          unsigned long long* trace = nullptr,
+                                          PairToken* tok = nullptr) {
+#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && group_tid<kPair>() == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
   constexpr bool kSpec = kEq >= 0;
@@ -513,29 +600,23 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const int nL = kHoist ? 3 : p.L;
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
-  // specialised one-wave kernels (D <= 2) have spare registers for loop invariants
-  constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0 && spec_derivs(kEq) <= 2;
-  const int tid = opaque((int)threadIdx.x);
-  const Lane ln = make_lane<kRows, kWR>(p, batch, tid);
+  // output-channel groups of four (final_layer4): the specialised kernels issue
+  // only the live ones (channels renumbered contiguously, DevParams::w_final4),
+  // the run-time-parameterised kernels all four (w_final4_pad)
+  constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 4;
+  // specialised one-wave integrators keep loop invariants in registers
+  constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0;
+  static_assert(!kPair || (kRows == 64 && kWR == 64), "paired groups are one-wave groups");
+  const int tid = opaque(group_tid<kPair>());
+  const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group_block<kPair>());
   if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][kKW];
-  int fin_rows[4][kKW];     // same for the output layer's four 16-row tiles
   if (!fixed) {
 #pragma unroll
     for (int t2 = 0; t2 < kWR / 32; ++t2)
       tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
-    if (!kKeepRows) {
-#pragma unroll
-      for (int t2 = 0; t2 < kWR / 16; ++t2)
-        tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 16 + (ln.lane & 15), p.N, fin_rows[t2]);
-    } else {
-#pragma unroll
-      for (int t2 = 0; t2 < 4; ++t2)
-#pragma unroll
-        for (int k = 0; k < kKW; ++k) fin_rows[t2][k] = res.fin_off[t2][k];
-    }
   }
   const float un_reg = u / p.stddev;   // model.py:450-451, a true division
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
@@ -544,7 +625,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // previous evaluation (or the launch prologue), published here
   // (after the barrier: slower wavefronts may still be reading sm.fk in the
   // epilogue of the previous evaluation; the next barrier orders the readers)
-  __syncthreads();
+  group_sync<kPair>();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
   if (p.forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
     sm.fk[(unsigned)res.frc_run >> 24] = res.fk_next;
@@ -566,57 +647,73 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
   for (int c = 0; c < 16; ++c) net[c] = 0.0f;
   if (!fixed) {
-    float wfin[kFinSteps];
-    // specialised one-wave kernels (D <= 2) have spare registers: part of the
-    // output layer's weights stays resident, the rest is fetched per evaluation
-    constexpr int kKept = (kOneWave && kHoist && kEq >= 0 && spec_derivs(kEq) <= 2) ? kFinKeep : 0;
-#pragma unroll
-    for (int s2 = 0; s2 < kKept; ++s2) wfin[s2] = res.w_fin[s2];
     DDD_STAMP(1);
     if (!(ablate & 16))
       input_layer<kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act);
     const bool frc_next = p.forced && fast_forcing && !(ablate & 65);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
-    {   // first taps of the output layer: in flight while the hidden layers run
-      const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
-#pragma unroll
-      for (int s2 = 0; s2 < kFinPrefetch; ++s2) wfin[s2] = wsrc[s2 * 64];
-    }
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
-      __syncthreads();
-      hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act);
+      group_sync<kPair>();
+      if constexpr (kPair) {
+        // two token blocks per hidden layer (operand groups 0-9 and 10-19)
+        tok->acquire();
+        hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act,
+                          [tok]() { tok->release(); tok->acquire(); });
+        tok->release();
+      } else {
+        hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act);
+      }
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
     {
-      const float* __restrict__ wsrc = p.w_final + opaque(ln.lane);
+      // output layer: weights resident (specialised one-wave integrators) or
+      // re-fetched from L2 here, in flight across the forcing sums below
+      float wf4[fin4_regs(kNG)];
+      int off4[kKW];
+      if (kKeepRows) {
 #pragma unroll
-      for (int s2 = (kKept > kFinPrefetch ? kKept : kFinPrefetch); s2 < kFinSteps; ++s2)
-        wfin[s2] = wsrc[s2 * 64];
-    }
-    // the output layer's weights are in flight from L2 and the hidden layer's
-    // last activations on their way to LDS: fill the wait with the forcing
-    // sums the next evaluation needs
-    if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
-    if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
-    __syncthreads();
-    final_layer<kWR, kKeepRows>(p, ln, in, out, wfin, fin_rows);
-    DDD_STAMP(3);
-    __syncthreads();
-    const float4* nrow = reinterpret_cast<const float4*>(out + ln.row * kHS);
+        for (int s2 = 0; s2 < fin4_regs(kNG); ++s2) wf4[s2] = res.w_fin4[s2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = nrow[q];
-      net[4 * q + 0] = v.x; net[4 * q + 1] = v.y;
-      net[4 * q + 2] = v.z; net[4 * q + 3] = v.w;
+        for (int k = 0; k < kKW; ++k) off4[k] = res.fin4_off[k];
+      } else {
+        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_pad) + opaque(ln.lane);
+#pragma unroll
+        for (int s2 = 0; s2 < fin4_regs(kNG); ++s2) wf4[s2] = wsrc[s2 * 64];
+        int rows5[kKW];
+        tap_rows<kRows == 64>(ln, ln.row, p.N, rows5);
+#pragma unroll
+        for (int k = 0; k < kKW; ++k)
+          off4[k] = (int)__umul24((unsigned)rows5[k], (unsigned)(kHS * 4));
+      }
+      // the hidden layer's last activations are on their way to LDS: fill the
+      // wait with the forcing sums the next evaluation needs
+      if (nL == 2) group_sync<kPair>();   // no hidden layer: phase 1 -> phase 2 ordering
+      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
+      group_sync<kPair>();
+      f32x4 acc4[kNG];
+      if (!(ablate & 4)) {
+        if constexpr (kPair) tok->acquire();
+        final_layer4<kNG>(in, wf4, off4, acc4);
+        if constexpr (kPair) tok->release();
+      } else {
+#pragma unroll
+        for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      }
+      DDD_STAMP(3);
+      // every lane holds its own row's channels: no LDS round trip, no barrier
+#pragma unroll
+      for (int g4 = 0; g4 < kNG; ++g4)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
     }
   } else {
     if (p.forced && fast_forcing && !(ablate & 65))
-      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
-    __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
+      res.fk_next = forcing_sums<kRows, kWR, kPair>(p, sm, res, t_next, tid);
+    group_sync<kPair>();   // all patch reads done before the next evaluation rewrites sm.u
   }
 
   // ---- projection onto the accuracy-constrained stencils + stencil apply -----
@@ -656,9 +753,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
     for (int g = 0; g < kGMax; ++g) cf[d][g] = 0.0f;
   if (!fixed && folded) {
-    // the output layer already applied the projection: channel 8 d + g
+    // the output layer already applied the projection: channel G d + g
+    // (specialised kernels, contiguous) or 8 d + g (padded packing)
+    if (kSpec) {
 #pragma unroll
-    for (int g = 0; g < kGMax; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
+      for (int g = 0; g < kGMax; ++g)
+        if (g < nG) { cf[0][g] = net[g]; cf[1][g] = net[nG + g]; }
+    } else {
+#pragma unroll
+      for (int g = 0; g < kGMax; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
+    }
   } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -726,7 +830,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
                                     : wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
       if (ln.owner) sm.flux[ln.row] = r;
-      __syncthreads();
+      group_sync<kPair>();
       fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     }
     r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
@@ -758,11 +862,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 }
 
 // Per-launch setup: resident registers and the per-sample tables in LDS.
-template <int kRows, int kWR, bool kHoist>
+template <int kRows, int kWR, bool kHoist, bool kPair = false>
 __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
                                              const Lane& ln, int batch, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
-  const int tid = threadIdx.x;
+  const int tid = group_tid<kPair>();
+  const int block = group_block<kPair>();
   const int spg = kRows / p.N;
   for (int i = tid; i < kTabRows * kGMax; i += kThreads) {
     const int rowi = i / kGMax, g = i % kGMax;
@@ -780,15 +885,14 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
     // (kHoist: the persistent kernels; a single fused substep has no loop)
     if (kHoist && kRows == 64 && kWR == 64) {
 #pragma unroll
-      for (int s = 0; s < kFinKeep; ++s) res.w_fin[s] = p.w_final[s * 64 + ln.lane];
-#pragma unroll
-      for (int t2 = 0; t2 < 4; ++t2) {
+      for (int s = 0; s < fin4_regs(4); ++s)   // buffer holds fin4_regs(4) rows (zero padded)
+        res.w_fin4[s] = p.w_final4[s * 64 + ln.lane];
+      {
         int rows[kKW];
-        tap_rows<true>(ln, t2 * 16 + (ln.lane & 15), p.N, rows);
+        tap_rows<true>(ln, ln.row, p.N, rows);
 #pragma unroll
         for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
-          res.fin_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
-                                      32 * (ln.lane >> 4));
+          res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
       }
       const int gl = p.G >> 1;
 #pragma unroll
@@ -808,7 +912,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
   for (int i = tid; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
   if (fast && tid < spg * p.P) {
     const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
-    const long sample = (long)blockIdx.x * spg + fsl;
+    const long sample = (long)block * spg + fsl;
     if (sample < batch) {
       const float4 q = p.frc[sample * p.P + (tid - fsl * p.P)];
       res.frc_a = q.x; res.frc_omega = q.y; res.frc_phi = q.z;
@@ -820,7 +924,7 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
   if (fast && tid < spg * p.n_k * 2) {
     const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
     const int kk = (tid >> 1) - sl * p.n_k;
-    const long sample = (long)blockIdx.x * spg + sl;
+    const long sample = (long)block * spg + sl;
     if (sample < batch) {
       const int m0 = p.runs[sample * 8 + kk], m1 = p.runs[sample * 8 + kk + 1];
       res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
@@ -838,7 +942,7 @@ template <int kRows, int kWR, int kEq = -1>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams p,
                                                                       SubstepArgs a) {
   __shared__ Shared<kRows, kWR> sm;
-  const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x);
+  const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
@@ -864,13 +968,38 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
 // kTrace: s_memtime phase stamps (DDD_TRACE_PTR, profiles/tools/trace_phases.py)
 // are compiled into the run-time-parameterised instantiation and into one
 // dedicated specialised instantiation only: their branches cost ~2 % otherwise.
-template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0)>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
-                                                                        IntegrateArgs a) {
-  __shared__ Shared<kRows, kWR> sm;
-  const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x);
+// kPair: eight token-paired one-wave groups per workgroup (PairToken), chosen by
+// the host when the batch gives every SIMD two wavefronts.
+template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0),
+          bool kPair = false>
+__global__ __launch_bounds__(kPair ? 64 * kPairWaves : kRows / kWR * 64, kPair ? 1 : 2)
+void integrate_kernel(DevParams p, IntegrateArgs a) {
+  __shared__ Shared<kRows, kWR> sms[kPair ? kPairWaves : 1];
+  __shared__ int pair_simd[kPairWaves];
+  __shared__ int pair_turn[kPairWaves];
+  Shared<kRows, kWR>& sm = sms[kPair ? (threadIdx.x >> 6) : 0];
+  PairToken tok{nullptr, 0};
+  if constexpr (kPair) {
+    // which two wavefronts of this workgroup share a SIMD?  (one workgroup
+    // fills its CU: LDS admits no second one, registers two wavefronts per SIMD)
+    const int w = threadIdx.x >> 6;
+    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_ID.simd_id
+    if ((threadIdx.x & 63) == 0) { pair_simd[w] = simd; pair_turn[w] = 0; }
+    __syncthreads();
+    int partner = -1, count = 0;
+#pragma unroll
+    for (int o = 0; o < kPairWaves; ++o)
+      if (pair_simd[o] == simd) { ++count; if (o != w) partner = o; }
+    if (count == 2 && a.prio_split != 8) {   // prio_split = 8: A/B switch, groups free-run
+      tok.turn = &pair_turn[w < partner ? w : partner];
+      tok.mine = w < partner ? 0 : 1;
+      // the later wavefront starts one block behind: its first turn is empty
+      if (w > partner) { tok.acquire(); tok.release(); }
+    }
+  }
+  const Lane ln = make_lane<kRows, kWR>(p, a.batch, group_tid<kPair>(), group_block<kPair>());
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
+  const bool fast_frc = launch_setup<kRows, kWR, kHoist, kPair>(p, sm, ln, a.batch, res);
   // Two wavefronts share each SIMD and run the same phases; left alone they
   // phase-lock (both in their MFMA phase, then both in their VALU phase, the
   // matrix pipe idling).  A static priority split by hardware wave slot lets
@@ -900,8 +1029,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
   size_t snap = 0;
   int evals = 0;
   if (fast_frc && !(ablate & 1))
-    res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
-                                           threadIdx.x);
+    res.fk_next = forcing_sums<kRows, kWR, kPair>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
+                                                  group_tid<kPair>());
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
     ST ynew = y;
@@ -911,16 +1040,16 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
       unsigned long long* tr = nullptr;
       if (kTrace && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
-        tr = a.trace + (size_t)blockIdx.x * kTraceSlots + evals * 5;
+        tr = a.trace + (size_t)group_block<kPair>() * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
       // next step): its forcing sums are prepared inside this evaluation
       const double tn = s + 1 < a.tab.stages
                             ? t + a.tab.c[s + 1] * a.dt
                             : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
-      const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(p, sm, a.batch, (float)us,
-                                              (float)(t + a.tab.c[s] * a.dt), (float)tn, res,
-                                              fast_frc, nullptr, nullptr, ablate, tr);
+      const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace, kPair>(
+          p, sm, a.batch, (float)us, (float)(t + a.tab.c[s] * a.dt), (float)tn, res, fast_frc,
+          nullptr, nullptr, ablate, tr, &tok);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
     }
@@ -931,6 +1060,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       ++snap;
     }
   }
+  if constexpr (kPair) tok.finish();   // the partner runs its remaining blocks freely
 }
 
 }  // namespace mfma

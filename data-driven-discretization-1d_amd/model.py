@@ -91,7 +91,9 @@ def forcing_kernel_tables(forcing: dict, grid: equations_lib.Grid) -> dict:
   n = grid.solution_num_points
   if grid.resample_method == 'mean' and rf > 1:
     delta = 2 * np.pi * k / (n * rf)
-    dirichlet = np.sin(rf * delta / 2) / (rf * np.sin(delta / 2))
+    # k = 0 (equation_kwargs k_min=0): a constant mode, block mean = itself
+    safe = np.where(k == 0, 1.0, delta)
+    dirichlet = np.where(k == 0, 1.0, np.sin(rf * safe / 2) / (rf * np.sin(safe / 2)))
     amplitude = a * dirichlet
     phase = phi + (rf - 1) * delta / 2
   else:
@@ -496,8 +498,12 @@ class LearnedStencilModel(_DeviceModel):
       # tower is stored; the null-space tables are rebuilt from the hparams
       # exactly as model.predict_coefficients does at restore time
       # (model.py:480-489) -- and, as there, depend on the local LAPACK's SVD.
-      kernels, conv_biases = checkpoint.load_conv_weights(checkpoint_dir,
-                                                          hparams.num_layers)
+      if hparams.num_layers == 0:
+        # the learned constant vector (model.py:496-499); KeyError if absent
+        const = checkpoint.load_constant_coefficients(checkpoint_dir)
+        return cls(equation, hparams, [], [], constant_coefficients=const)
+      kernels, conv_biases = checkpoint.load_conv_weights(
+          checkpoint_dir, hparams.num_layers, hparams.model_target)
       return cls(equation, hparams, kernels, conv_biases)
     with np.load(os.path.join(checkpoint_dir, WEIGHTS_FILENAME)) as data:
       kernels = [data['conv{}_kernel'.format(i)]
@@ -781,13 +787,30 @@ def baseline_space_derivatives(inputs, equation, accuracy_order: int = 1):
 
 def integrate_ode(model: _DeviceModel, inputs, num_time_steps: int,
                   time_step: float):
-  """model.py:138-159: midpoint rule, result [batch, x, num_time_steps]."""
+  """model.py:138-159: midpoint rule, result [batch, x, num_time_steps].
+
+  The reference takes ``func(y, t)``; here the model is the function: its
+  right-hand side includes ``finalize_time_derivative`` (forcing at time t)
+  when forcing has been set on the model, and not otherwise."""
   out = model.integrate_fixed(inputs, num_time_steps, dt=time_step,
                               scheme='midpoint')
   return out.permute(1, 2, 0)
 
 
 def predict_time_evolution(inputs, model: LearnedStencilModel):
-  """model.py:643-661 (uses hparams.num_time_steps and equation.time_step)."""
+  """model.py:643-661 (uses hparams.num_time_steps and equation.time_step).
+
+  The reference's function drops ``t`` and integrates
+  ``predict_time_derivative`` -- the equation of motion WITHOUT
+  ``finalize_time_derivative`` (no forcing, model.py:655-657).  A model that
+  has device forcing set would integrate a different right-hand side, so, like
+  ``predict_time_derivative``, this refuses to run then; use
+  ``integrate_ode(model, ...)`` / ``model.integrate_fixed`` for the forced
+  trajectory.
+  """
+  if model._forcing is not None:
+    raise ValueError('predict_time_evolution excludes forcing (model.py:655-657); '
+                     'call model.set_forcing(None) first, or use integrate_ode / '
+                     'model.integrate_fixed for the forced trajectory')
   return integrate_ode(model, inputs, model.hparams.num_time_steps,
                        model.equation.time_step)

@@ -9,7 +9,7 @@ m = model_lib.LearnedStencilModel(eq, hp)
 m.set_forcing(model_lib.batched_forcing_parameters(range(B), nparams=20))
 y0 = torch.randn(B, 64, device='cuda') * 0.3
 trace = torch.zeros(B * 256, dtype=torch.int64, device='cuda')
-os.environ['DDD_TRACE_PTR'] = str(trace.data_ptr())
+ddd1d_amd._lib.debug_set_option('trace_ptr', trace.data_ptr())
 m.integrate_fixed(y0, 25, dt=1e-3, save_every=25)
 torch.cuda.synchronize()
 tr = trace.cpu().numpy().reshape(B, 256)[:, :250].reshape(B, 50, 5)

@@ -2,15 +2,15 @@
 
 Transcribes, formula by formula, (a) the weight packing of
 csrc/capi.hip::pack_mfma_weights, (b) the operand gathers / result scatters of
-csrc/rhs_mfma.h (input_layer, hidden_layer, final_layer) and (c) the CDNA4
+csrc/rhs_mfma.h (input_layer, hidden_layer, final_layer4) and (c) the CDNA4
 f32 MFMA register layouts the kernels assume
 (cdna_hip_programming.md section 3):
 
   v_mfma_f32_32x32x2_f32 : lane l supplies A[i = l & 31][k = l >> 5] and
       B[k = l >> 5][j = l & 31]; register r of lane l holds
       D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
-  v_mfma_f32_16x16x4_f32 : lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15];
-      register r of lane l holds D[4 (l >> 4) + r][l & 15].
+  v_mfma_f32_4x4x1_16b_f32, cbsz = 4, abid = b : register r of lane l
+      accumulates A(lane 4 b + r) * B(lane l).
 
 and checks that the composition equals the oracle's conv tower.  The layouts
 themselves are verified on hardware by ddd_selftest_mfma_layout.
@@ -40,15 +40,6 @@ def mfma32(a, b, acc):
   return acc
 
 
-def mfma16(a, b, acc):
-  A = a.reshape(4, 16).T.astype(np.float64)      # [i, k]: lane = i + 16 k
-  B = b.reshape(4, 16).astype(np.float64)        # [k, j]: lane = j + 16 k
-  D = A @ B
-  for r in range(4):
-    acc[:, r] += D[4 * (LANES >> 4) + r, LANES & 15]
-  return acc
-
-
 def pack_input(w, b):          # capi.hip: input layer
   packed = np.zeros((3, 64))
   for s in range(3):
@@ -67,19 +58,6 @@ def pack_hidden(w, b):         # capi.hip: hidden layer
       packed[s, lane] = w[tap, cin, cout]
   for lane in range(64):
     packed[80, lane] = b[lane & 31] if (lane >> 5) == 0 else 0.0
-  return packed
-
-
-def pack_final(w, b, c_out):   # capi.hip: output layer
-  packed = np.zeros((41, 64))
-  for s in range(40):
-    tap, jj = s // 8, s % 8
-    for lane in range(64):
-      cin, cout = 8 * (lane >> 4) + jj, lane & 15
-      packed[s, lane] = w[tap, cin, cout] if cout < c_out else 0.0
-  for lane in range(64):
-    cout = lane & 15
-    packed[40, lane] = b[cout] if ((lane >> 4) == 0 and cout < c_out) else 0.0
   return packed
 
 
@@ -138,21 +116,8 @@ def emulate_tower(un_rows, n, kernels, biases, c_out):
         acc = mfma32(w_h[80], np.ones(64), acc)
         store_tile32(dst, trow, half, relu(acc))
     src, dst = dst, src
-  # ---- output layer ----------------------------------------------------------
-  w_f = pack_final(kernels[-1], biases[-1], c_out)
-  for wave in range(4):
-    j, quarter = LANES & 15, LANES >> 4
-    for t in range(4):
-      trow = wave * 64 + t * 16 + j
-      acc = np.zeros((64, 4))
-      for tap in range(5):
-        rows = tile_src_row(trow, tap - 2, n, rows_used)
-        for i in range(8):
-          acc = mfma16(w_f[tap * 8 + i], src[rows, 8 * quarter + i], acc)
-      acc = mfma16(w_f[40], np.ones(64), acc)
-      for r in range(4):
-        dst[trow, 4 * quarter + r] = acc[:, r]
-  return dst[:, :16]
+  # ---- output layer (run-time-parameterised kernels: 4 padded groups) ---------
+  return emulate_final4(src, n, kernels[-1], biases[-1], c_out, groups=4)
 
 
 @pytest.mark.parametrize('n,num_layers,c_out', [(64, 3, 9), (32, 3, 11),
@@ -176,3 +141,81 @@ def test_emulated_tower_matches_oracle(n, num_layers, c_out):
   np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
   # padded output channels stay exactly zero
   assert np.all(net[:samples * n, c_out:] == 0)
+
+
+# ---------------------------------------------------------------------------
+# Output layer on v_mfma_f32_4x4x1_16b_f32 with the A block broadcast
+# (rhs_mfma.h::final_layer4, capi.hip: "packed4").  Assumed layout (verified
+# on hardware by ddd_selftest_mfma_layout): with cbsz = 4 / abid = b, register
+# r of lane l accumulates A(lane 4 b + r) * B(lane l).
+# ---------------------------------------------------------------------------
+FIN4_K = 161
+
+
+def fin4_regs(groups):
+  return (FIN4_K * groups + 15) // 16
+
+
+def pack_final4(w, b, n_ch, groups=None):   # capi.hip: pack4(groups, renumber)
+  groups = groups or (n_ch + 3) // 4
+  packed = np.zeros((fin4_regs(4), 64))
+  wk = w.reshape(160, -1)
+  for k in range(FIN4_K):
+    for grp in range(groups):
+      q = k * groups + grp
+      for r in range(4):
+        ch = 4 * grp + r
+        if ch >= n_ch:
+          continue
+        packed[q // 16, 4 * (q % 16) + r] = wk[k, ch] if k < 160 else b[ch]
+  return packed, groups
+
+
+def mfma4(a, bop, acc, abid):
+  for r in range(4):
+    acc[:, r] += a[4 * abid + r] * bop
+  return acc
+
+
+def emulate_final4(src, n, w, b, n_ch, groups=None):
+  """src: [256, 36] hidden activations.  Returns net [256, 4 * groups]."""
+  rows_used = (ROWS // n) * n
+  packed, groups = pack_final4(w, b, n_ch, groups)
+  out = np.zeros((ROWS, 4 * groups))
+  for wave in range(4):
+    row = wave * 64 + LANES
+    acc = [np.zeros((64, 4)) for _ in range(groups)]
+    for og in range(40):
+      tap, c4 = og // 8, og % 8
+      rows = tile_src_row(row, tap - 2, n, rows_used)
+      for e in range(4):
+        bop = src[rows, 4 * c4 + e]
+        for grp in range(groups):
+          q = (og * 4 + e) * groups + grp
+          acc[grp] = mfma4(packed[q // 16], bop, acc[grp], q % 16)
+    for grp in range(groups):
+      q = 160 * groups + grp
+      acc[grp] = mfma4(packed[q // 16], np.ones(64), acc[grp], q % 16)
+    for grp in range(groups):
+      out[row, 4 * grp:4 * grp + 4] = acc[grp]
+  return out
+
+
+@pytest.mark.parametrize('n,n_ch', [(64, 12), (64, 14), (32, 11), (256, 11), (128, 12),
+                                    (100, 9)])
+def test_emulated_final4_matches_direct_conv(n, n_ch):
+  rs = np.random.RandomState(n + n_ch)
+  w = rs.randn(5, 32, n_ch) * 0.3
+  b = rs.randn(n_ch) * 0.1
+  samples = ROWS // n
+  h = rs.randn(samples, n, 32)
+  src = np.zeros((ROWS, HS))
+  src[:samples * n, :32] = h.reshape(-1, 32)
+  src[:, 32:] = 7.0   # row padding (forcing trig table in the kernel): never read
+  got = emulate_final4(src, n, w, b, n_ch)[:samples * n].reshape(samples, n, -1)
+  want = np.zeros((samples, n, n_ch))
+  for tap in range(5):
+    want += np.einsum('bxc,cf->bxf', np.roll(h, 2 - tap, axis=1), w[tap])
+  want += b
+  np.testing.assert_allclose(got[..., :n_ch], want, rtol=1e-12, atol=1e-12)
+  assert np.all(got[..., n_ch:] == 0)
