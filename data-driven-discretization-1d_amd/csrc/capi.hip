@@ -153,6 +153,7 @@ struct ddd_model {
   int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
+  bool last_launch_paired = false;   // the most recent persistent launch used token-paired groups
   const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
@@ -561,6 +562,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
 template <int kRows, int kWR, typename ST>
 void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
   m->dp.dpp_rol = dpp_wave_rol_ok();
+  m->last_launch_paired = false;
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
@@ -573,6 +575,40 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
                          block, 0, stream, m->dp, a);                                  \
       return;
     int eq = spec_equation(m);
+    if constexpr (kRows == 64) {
+      // Token-paired groups (rhs_mfma.h: PairToken) once the batch gives every
+      // SIMD two wavefronts: eight one-wave groups per workgroup, the two on
+      // each SIMD alternate their MFMA blocks.
+      const int groups = blocks;
+      if (eq >= 0 && !g_debug.no_pair && !m->explicit_kernel && groups >= 2 * device_simds()) {
+        const dim3 pgrid((groups + ddd::mfma::kPairWaves - 1) / ddd::mfma::kPairWaves);
+        const dim3 pblock(64 * ddd::mfma::kPairWaves);
+        m->last_launch_paired = true;
+        if (a.trace != nullptr && eq == ddd::EQ_BURGERS_CONS) {
+          // token statistics: [groups][8] words (profiles/tools/pair_stats.py)
+          hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true,
+                                                          ddd::EQ_BURGERS_CONS, true, true>),
+                             pgrid, pblock, 0, stream, m->dp, a);
+          return;
+        }
+#define DDD_PAIR_CASE(EQ)                                                                 \
+        case EQ:                                                                          \
+          hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true, EQ, false, \
+                                                          true>),                         \
+                             pgrid, pblock, 0, stream, m->dp, a);                         \
+          return;
+        switch (eq) {
+          DDD_PAIR_CASE(ddd::EQ_BURGERS)
+          DDD_PAIR_CASE(ddd::EQ_BURGERS_CONS)
+          DDD_PAIR_CASE(ddd::EQ_KDV)
+          DDD_PAIR_CASE(ddd::EQ_KDV_CONS)
+          DDD_PAIR_CASE(ddd::EQ_KS)
+          DDD_PAIR_CASE(ddd::EQ_KS_CONS)
+          default: break;
+        }
+#undef DDD_PAIR_CASE
+      }
+    }
     if (a.trace != nullptr) {
       // phase tracing: the dedicated traced instantiation (headline config) or
       // the run-time-parameterised kernel
@@ -1297,7 +1333,8 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
-  return geo.wave_rows == 32 ? "mfma_f32_r64w32" : "mfma_f32_r64";
+  if (geo.wave_rows == 32) return "mfma_f32_r64w32";
+  return m->last_launch_paired ? "mfma_f32_r64_paired" : "mfma_f32_r64";
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
@@ -1335,6 +1372,46 @@ int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
   DDD_HIP(hipGetLastError());
   DDD_HIP(hipMemcpy(out_host, d, (size_t)blocks * 4 * sizeof(unsigned), hipMemcpyDeviceToHost));
   (void)hipFree(d);
+  return DDD_OK;
+}
+
+// Issue-port sharing probe (ops.h: issue_share_probe_kernel).  Returns mean
+// s_memtime ticks per operation for the MFMA streamers (slot 0) and the
+// workers (slot 1) over `blocks` workgroups.
+int ddd_debug_issue_share(int mfma_kind, int work_kind, int blocks, int iters, int prio,
+                          double* mfma_ticks_per_op, double* work_ticks_per_op) {
+  unsigned long long* d = nullptr;
+  const size_t words = (size_t)blocks * 8 * 4;
+  DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d), words * sizeof(unsigned long long)));
+  DDD_HIP(hipMemset(d, 0, words * sizeof(unsigned long long)));
+#define DDD_SHARE(M, W)                                                                  \
+  if (mfma_kind == M && work_kind == W)                                                  \
+    hipLaunchKernelGGL((ddd::ops::issue_share_probe_kernel<M, W>), dim3(blocks), dim3(512), \
+                       0, nullptr, d, iters, 1.0f, prio);
+  for (int rep = 0; rep < 2; ++rep) {
+    DDD_SHARE(0, 1) DDD_SHARE(0, 2) DDD_SHARE(0, 3) DDD_SHARE(0, 4)
+    DDD_SHARE(1, 0) DDD_SHARE(1, 1) DDD_SHARE(1, 2) DDD_SHARE(1, 3) DDD_SHARE(1, 4)
+    DDD_SHARE(2, 0) DDD_SHARE(2, 1) DDD_SHARE(2, 2) DDD_SHARE(2, 3) DDD_SHARE(2, 4)
+    DDD_SHARE(3, 0) DDD_SHARE(3, 1) DDD_SHARE(3, 2) DDD_SHARE(4, 0) DDD_SHARE(4, 1) DDD_SHARE(4, 2)
+    DDD_SHARE(5, 0) DDD_SHARE(5, 1) DDD_SHARE(5, 2) DDD_SHARE(5, 3) DDD_SHARE(6, 0) DDD_SHARE(6, 1) DDD_SHARE(6, 2)
+    DDD_SHARE(7, 0) DDD_SHARE(7, 1) DDD_SHARE(7, 2) DDD_SHARE(8, 0) DDD_SHARE(8, 1) DDD_SHARE(8, 2) DDD_SHARE(8, 3)
+    DDD_HIP(hipDeviceSynchronize());
+  }
+#undef DDD_SHARE
+  DDD_HIP(hipGetLastError());
+  std::vector<unsigned long long> h(words);
+  DDD_HIP(hipMemcpy(h.data(), d, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  double sm = 0, sw = 0;
+  long nm = 0, nw = 0;
+  for (size_t g = 0; g < (size_t)blocks * 8; ++g) {
+    const unsigned slot = (unsigned)(h[g * 4 + 1] & 0xff);
+    if (slot == 0) { sm += (double)h[g * 4]; ++nm; } else { sw += (double)h[g * 4]; ++nw; }
+  }
+  const double mops = (double)iters * ((mfma_kind == 2 || mfma_kind >= 7) ? 256.0 : 64.0);
+  const double wops = (double)iters * 64.0;
+  *mfma_ticks_per_op = nm ? sm / nm / mops : 0.0;
+  *work_ticks_per_op = nw ? sw / nw / wops : 0.0;
   return DDD_OK;
 }
 

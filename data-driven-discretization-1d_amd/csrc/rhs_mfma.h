@@ -138,37 +138,48 @@ __device__ __forceinline__ void group_sync() {
   }
 }
 
-struct PairToken {
-  int* turn;   // LDS word of this SIMD's pair; nullptr: free-running
-  int mine;    // turn value at which this wavefront runs its next MFMA block
+typedef __attribute__((address_space(3))) int lds_int;
 
-  __device__ __forceinline__ bool paired() const {
-    return __builtin_amdgcn_readfirstlane((int)(turn != nullptr)) != 0;
-  }
+struct PairToken {
+  lds_int* turn;   // LDS word of this SIMD's pair (wave-uniform)
+  int mine;    // turn value at which this wavefront runs its next MFMA block (wave-uniform)
+  int on;      // 0: free-running (not paired, or the pair dissolved)
+  // profiling (traced instantiation only): cycles spent waiting, polls, acquisitions
+  unsigned long long waited;
+  int polls, acquires, timeouts, stats;
+
   // Spin (s_sleep between LDS polls) until it is this wavefront's turn.  A
   // bounded wait: a partner that never shows up (it cannot, but a hang would
   // take the GPU with it) dissolves the pair instead.
   __device__ __forceinline__ void acquire() {
-    if (!paired()) return;
+    if (!on) return;
     __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0ull;
     int spins = 0;
-    while (__builtin_amdgcn_readfirstlane(*(volatile int*)turn) < mine) {
+    while (__builtin_amdgcn_readfirstlane(*(volatile lds_int*)turn) < mine) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 16)) { finish(); break; }
+      if (++spins > (1 << 16)) { finish(); ++timeouts; break; }
+    }
+    if (stats) {
+      waited += __builtin_amdgcn_s_memtime() - t0;
+      polls += spins;
+      ++acquires;
     }
     __builtin_amdgcn_sched_barrier(0);
   }
   __device__ __forceinline__ void release() {
-    if (!paired()) return;
+    if (!on) return;
     __builtin_amdgcn_sched_barrier(0);
-    if ((threadIdx.x & 63) == 0) atomicMax(turn, mine + 1);   // never lowers kTokenFree
+    if ((threadIdx.x & 63) == 0)   // max: never lowers kTokenFree
+      __hip_atomic_fetch_max(turn, mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     mine += 2;
     __builtin_amdgcn_sched_barrier(0);
   }
   __device__ __forceinline__ void finish() {
-    if (!paired()) return;
-    if ((threadIdx.x & 63) == 0) atomicMax(turn, kTokenFree);
-    turn = nullptr;
+    if (!on) return;
+    if ((threadIdx.x & 63) == 0)
+      __hip_atomic_fetch_max(turn, kTokenFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    on = 0;
   }
 };
 
@@ -978,11 +989,13 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
   __shared__ int pair_simd[kPairWaves];
   __shared__ int pair_turn[kPairWaves];
   Shared<kRows, kWR>& sm = sms[kPair ? (threadIdx.x >> 6) : 0];
-  PairToken tok{nullptr, 0};
+  PairToken tok{(lds_int*)pair_turn, 0, 0, 0ull, 0, 0, 0, (kPair && kTrace && a.trace != nullptr) ? 1 : 0};
+  const unsigned long long t_begin = (kPair && kTrace) ? __builtin_amdgcn_s_memtime() : 0ull;
+  int pair_info = 0;
   if constexpr (kPair) {
     // which two wavefronts of this workgroup share a SIMD?  (one workgroup
     // fills its CU: LDS admits no second one, registers two wavefronts per SIMD)
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_ID.simd_id
     if ((threadIdx.x & 63) == 0) { pair_simd[w] = simd; pair_turn[w] = 0; }
     __syncthreads();
@@ -990,9 +1003,14 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
 #pragma unroll
     for (int o = 0; o < kPairWaves; ++o)
       if (pair_simd[o] == simd) { ++count; if (o != w) partner = o; }
+    // (all values below are wave-uniform: keep them in scalar registers)
+    count = __builtin_amdgcn_readfirstlane(count);
+    partner = __builtin_amdgcn_readfirstlane(partner);
+    pair_info = simd | (count << 4) | ((partner & 0xf) << 8) | (w << 12);
     if (count == 2 && a.prio_split != 8) {   // prio_split = 8: A/B switch, groups free-run
-      tok.turn = &pair_turn[w < partner ? w : partner];
+      tok.turn = (lds_int*)&pair_turn[w < partner ? w : partner];
       tok.mine = w < partner ? 0 : 1;
+      tok.on = 1;
       // the later wavefront starts one block behind: its first turn is empty
       if (w > partner) { tok.acquire(); tok.release(); }
     }
@@ -1039,7 +1057,7 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
       unsigned long long* tr = nullptr;
-      if (kTrace && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
+      if (kTrace && !kPair && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
         tr = a.trace + (size_t)group_block<kPair>() * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
@@ -1061,6 +1079,19 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
     }
   }
   if constexpr (kPair) tok.finish();   // the partner runs its remaining blocks freely
+  if constexpr (kPair && kTrace) {
+    if (a.trace != nullptr && (threadIdx.x & 63) == 0) {
+      unsigned long long* tr = a.trace + (size_t)group_block<kPair>() * 8;
+      tr[0] = (unsigned long long)pair_info;
+      tr[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+      tr[2] = tok.waited;
+      tr[3] = (unsigned long long)tok.polls;
+      tr[4] = (unsigned long long)tok.acquires;
+      tr[5] = (unsigned long long)tok.timeouts;
+      tr[6] = __builtin_amdgcn_s_memtime() - t_begin;
+      tr[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+    }
+  }
 }
 
 }  // namespace mfma
