@@ -33,7 +33,6 @@ struct DebugOptions {
   int no_fold = 0;       // keep the projection out of the output layer (D <= 2 models)
   int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
   int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
-  int no_pair = 0;       // free-running one-wave groups instead of token-paired ones
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
   int ablate = 0;        // skips kernel phases: WRONG RESULTS (run-time-parameterised kernels)
@@ -153,7 +152,6 @@ struct ddd_model {
   int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
-  bool last_launch_paired = false;   // the most recent persistent launch used token-paired groups
   const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
@@ -562,7 +560,6 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
 template <int kRows, int kWR, typename ST>
 void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
   m->dp.dpp_rol = dpp_wave_rol_ok();
-  m->last_launch_paired = false;
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
@@ -575,40 +572,6 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
                          block, 0, stream, m->dp, a);                                  \
       return;
     int eq = spec_equation(m);
-    if constexpr (kRows == 64) {
-      // Token-paired groups (rhs_mfma.h: PairToken) once the batch gives every
-      // SIMD two wavefronts: eight one-wave groups per workgroup, the two on
-      // each SIMD alternate their MFMA blocks.
-      const int groups = blocks;
-      if (eq >= 0 && !g_debug.no_pair && !m->explicit_kernel && groups >= 2 * device_simds()) {
-        const dim3 pgrid((groups + ddd::mfma::kPairWaves - 1) / ddd::mfma::kPairWaves);
-        const dim3 pblock(64 * ddd::mfma::kPairWaves);
-        m->last_launch_paired = true;
-        if (a.trace != nullptr && eq == ddd::EQ_BURGERS_CONS) {
-          // token statistics: [groups][8] words (profiles/tools/pair_stats.py)
-          hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true,
-                                                          ddd::EQ_BURGERS_CONS, true, true>),
-                             pgrid, pblock, 0, stream, m->dp, a);
-          return;
-        }
-#define DDD_PAIR_CASE(EQ)                                                                 \
-        case EQ:                                                                          \
-          hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true, EQ, false, \
-                                                          true>),                         \
-                             pgrid, pblock, 0, stream, m->dp, a);                         \
-          return;
-        switch (eq) {
-          DDD_PAIR_CASE(ddd::EQ_BURGERS)
-          DDD_PAIR_CASE(ddd::EQ_BURGERS_CONS)
-          DDD_PAIR_CASE(ddd::EQ_KDV)
-          DDD_PAIR_CASE(ddd::EQ_KDV_CONS)
-          DDD_PAIR_CASE(ddd::EQ_KS)
-          DDD_PAIR_CASE(ddd::EQ_KS_CONS)
-          default: break;
-        }
-#undef DDD_PAIR_CASE
-      }
-    }
     if (a.trace != nullptr) {
       // phase tracing: the dedicated traced instantiation (headline config) or
       // the run-time-parameterised kernel
@@ -1333,8 +1296,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
-  if (geo.wave_rows == 32) return "mfma_f32_r64w32";
-  return m->last_launch_paired ? "mfma_f32_r64_paired" : "mfma_f32_r64";
+  return geo.wave_rows == 32 ? "mfma_f32_r64w32" : "mfma_f32_r64";
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
@@ -1347,14 +1309,13 @@ const char* ddd_debug_last_substep_kernel(const ddd_model* m) {
 
 // Profiling / A-B switches (not part of the product API; every change is
 // logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
-// no_stream, no_pair, prio_split, stagger, ablate, trace_ptr.
+// no_stream, prio_split, stagger, ablate, trace_ptr.
 int ddd_debug_set_option(const char* name, long long value) {
   if (name == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "name is NULL");
   const std::string key(name);
   if (key == "no_fold") g_debug.no_fold = (int)value;
   else if (key == "no_spec") g_debug.no_spec = (int)value;
   else if (key == "no_stream") g_debug.no_stream = (int)value;
-  else if (key == "no_pair") g_debug.no_pair = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;
   else if (key == "ablate") g_debug.ablate = (int)value;

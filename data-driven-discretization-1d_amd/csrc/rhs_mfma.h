@@ -60,7 +60,7 @@ struct Shared {
   float u[kRows];
   float un[kRows];                // u / standard_deviation (input-layer operand)
   float flux[kRows == kWR ? 1 : kRows];  // one-wave groups exchange flux by shuffle
-  float2 pm[kPmMax];              // per (sample, mode): a sin(psi), a cos(psi)
+  float2 pm[kPmMax + 8];          // per (sample, mode): a sin(psi), a cos(psi); + read-ahead padding
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
   float tab[kTabRows * kGMax];    // [0,4): bias8[d][8]; [4,20): ns8 rows per channel
 };
@@ -97,91 +97,6 @@ __host__ __device__ constexpr int spec_fin_channels(int eq) {
 }
 __host__ __device__ constexpr int spec_fin_groups(int eq) { return (spec_fin_channels(eq) + 3) / 4; }
 __host__ __device__ constexpr int fin4_regs(int groups) { return (kFin4K * groups + 15) / 16; }
-
-// ---------------------------------------------------------------------------
-// Token-paired wavefronts (kPair).  Two wavefronts share each SIMD; both run
-// the same program, and left alone they fall into lock step -- both in their
-// MFMA phases (sharing the pipe), then both in their VALU / LDS gaps with the
-// matrix pipe idle: measured, a co-resident pair costs 2 x MFMA time + the
-// gaps, hardly better than running the two one after the other.  A paired
-// workgroup holds EIGHT independent one-wave groups (one sample each at
-// N = 64) = two per SIMD of its CU; the two that landed on the same SIMD
-// (HW_ID.simd_id) pass a token through one LDS word and run their MFMA blocks
-// strictly alternately:
-//     A.hidden[0:10)  B.output  A.hidden[10:20)  B.hidden[0:10)  A.output  B.hidden[10:20) ...
-// so that every VALU / LDS gap of one wavefront (layer boundary, epilogue,
-// Runge-Kutta update, next input layer) lies under an MFMA block of the other.
-// The groups share nothing else: a "group" below is one wavefront with its own
-// Shared block; group_sync is a wavefront-local fence.
-// ---------------------------------------------------------------------------
-constexpr int kPairWaves = 8;       // one-wave groups per paired workgroup
-constexpr int kTokenFree = 1 << 30; // turn value that releases the partner for good
-
-template <bool kPair>
-__device__ __forceinline__ int group_tid() {
-  return kPair ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-}
-template <bool kPair>
-__device__ __forceinline__ int group_block() {
-  return kPair ? (int)(blockIdx.x * kPairWaves + (threadIdx.x >> 6)) : (int)blockIdx.x;
-}
-template <bool kPair>
-__device__ __forceinline__ void group_sync() {
-  if (kPair) {
-    // one wavefront: its LDS operations execute in order, only the compiler
-    // must not move accesses across
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  } else {
-    __syncthreads();
-  }
-}
-
-typedef __attribute__((address_space(3))) int lds_int;
-
-struct PairToken {
-  lds_int* turn;   // LDS word of this SIMD's pair (wave-uniform)
-  int mine;    // turn value at which this wavefront runs its next MFMA block (wave-uniform)
-  int on;      // 0: free-running (not paired, or the pair dissolved)
-  // profiling (traced instantiation only): cycles spent waiting, polls, acquisitions
-  unsigned long long waited;
-  int polls, acquires, timeouts, stats;
-
-  // Spin (s_sleep between LDS polls) until it is this wavefront's turn.  A
-  // bounded wait: a partner that never shows up (it cannot, but a hang would
-  // take the GPU with it) dissolves the pair instead.
-  __device__ __forceinline__ void acquire() {
-    if (!on) return;
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t0 = stats ? __builtin_amdgcn_s_memtime() : 0ull;
-    int spins = 0;
-    while (__builtin_amdgcn_readfirstlane(*(volatile lds_int*)turn) < mine) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 16)) { finish(); ++timeouts; break; }
-    }
-    if (stats) {
-      waited += __builtin_amdgcn_s_memtime() - t0;
-      polls += spins;
-      ++acquires;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ void release() {
-    if (!on) return;
-    __builtin_amdgcn_sched_barrier(0);
-    if ((threadIdx.x & 63) == 0)   // max: never lowers kTokenFree
-      __hip_atomic_fetch_max(turn, mine + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    mine += 2;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  __device__ __forceinline__ void finish() {
-    if (!on) return;
-    if ((threadIdx.x & 63) == 0)
-      __hip_atomic_fetch_max(turn, kTokenFree, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    on = 0;
-  }
-};
 
 struct Lane {
   int row;       // row inside the workgroup this lane owns in VALU phases
@@ -337,31 +252,50 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
 //   B: lane l supplies un[(pos(l & 31) + k - 2) mod N], un = u / std   (k = 5: 1.0)
 // kShfl (one-wave groups: row == lane): operands come from the lanes' `un`
 // registers by ds_bpermute instead of an LDS write + read round trip.
-template <int kWR, bool kShfl>
+// kAddr (specialised one-wave integrators): `bperm` holds the six ds_bpermute
+// byte addresses, resident for the launch; all six permutes are issued before
+// the first MFMA (one LDS-crossbar latency instead of six).
+template <int kWR, bool kShfl, bool kAddr = false>
 __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             const float* __restrict__ us, float un,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps],
-                                            const int (&rows)[2][kKW], int act) {
+                                            const int (&rows)[2][kKW], int act,
+                                            const int (*bperm)[3] = nullptr) {
   constexpr int kT = kWR / 32;
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
   f32x16 acc[kT];
+  float b0[kT], b1[kT], b2[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
-    const int r0 = half ? rows[t][1] : rows[t][0];              // taps 0 / 1
-    const int r1 = half ? rows[t][3] : rows[t][2];              // taps 2 / 3
-    const int r2 = rows[t][4];                                  // tap 4 / bias row
-    const float b0 = kShfl ? __shfl(un, r0, 64) : us[r0];
-    const float b1 = kShfl ? __shfl(un, r1, 64) : us[r1];
-    const float v2 = kShfl ? __shfl(un, r2, 64) : us[r2];
-    const float b2 = half ? 1.0f : v2;
+    if (kAddr) {
+      const int uni = __float_as_int(un);
+      b0[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][0], uni));
+      b1[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][1], uni));
+      b2[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][2], uni));
+    } else {
+      const int r0 = half ? rows[t][1] : rows[t][0];              // taps 0 / 1
+      const int r1 = half ? rows[t][3] : rows[t][2];              // taps 2 / 3
+      const int r2 = rows[t][4];                                  // tap 4 / bias row
+      b0[t] = kShfl ? __shfl(un, r0, 64) : us[r0];
+      b1[t] = kShfl ? __shfl(un, r1, 64) : us[r1];
+      b2[t] = kShfl ? __shfl(un, r2, 64) : us[r2];
+    }
+    b2[t] = half ? 1.0f : b2[t];
+  }
+  if (kAddr) __builtin_amdgcn_sched_group_barrier(0x080, 3 * kT, 0);   // the permutes first
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    acc[t] = DDD_MFMA32(w[0], b0, acc[t]);
-    acc[t] = DDD_MFMA32(w[1], b1, acc[t]);
-    acc[t] = DDD_MFMA32(w[2], b2, acc[t]);
   }
+#pragma unroll
+  for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[0], b0[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[1], b1[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[2], b2[t], acc[t]);
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     activate16(acc[t], act);
@@ -375,16 +309,14 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
 //   reduction index    : step s = 16 tap + jj, half = l >> 5  <->  (tap, cin = 16 half + jj)
 // The 16 floats a lane needs per tap are four ds_read_b128; the read of group
 // g + 1 is issued before the four MFMAs of group g (software prefetch).
-// `mid` runs between operand groups 9 and 10 (paired kernels: token hand-over).
-struct NoMid { __device__ __forceinline__ void operator()() const {} };
-
-template <int kWR, typename Mid = NoMid>
+// kByteOffsets: `rows` already holds the LDS byte offsets of the operand rows
+// (row * 144 + 64 * half; kept resident by the specialised one-wave integrators).
+template <int kWR, bool kByteOffsets = false>
 __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
-                                             const int (&rows)[2][kKW], int act,
-                                             Mid mid = Mid()) {
+                                             const int (&rows)[2][kKW], int act) {
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -395,7 +327,9 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int tap = 0; tap < kKW; ++tap)
-      rowo[t][tap] = (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) + 64 * half;   // bytes; rows < 256
+      rowo[t][tap] = kByteOffsets ? rows[t][tap]
+                                  : (int)__umul24((unsigned)rows[t][tap], (unsigned)(kHS * 4)) +
+                                        64 * half;   // bytes; rows < 256
   const auto operand = [&](int t, int tap, int q) {   // one v_mad_u32_u24 per row, q in the DS offset field
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) + rowo[t][tap] + 16 * q);
   };
@@ -428,7 +362,6 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
     // schedule: read group g+1 of every tile, then the MFMAs of group g
     __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);       // DS reads
     __builtin_amdgcn_sched_group_barrier(0x008, 4 * kT, 0);   // MFMAs
-    if (g == 9) mid();
   }
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
@@ -526,6 +459,8 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
 struct Resident {
   float w_fin4[fin4_regs(4)];   // output layer weights (specialised one-wave integrators)
   int fin4_off[kKW];        // LDS byte offsets of this lane's five tap rows (same kernels)
+  int hid_off[2][kKW];      // LDS byte offsets of the hidden layer's operand rows (same kernels)
+  int in_perm[2][3];        // ds_bpermute addresses of the input layer's operands (same kernels)
   int pch_idx[kGMax];       // indices into Shared::u of this row's stencil patch (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
@@ -563,21 +498,22 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Re
   float acc = 0.0f;
   // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
   // entries past the run add an exact 0, so the sum keeps mode order
+  // (reads past the run stay inside Shared::pm: it carries 8 entries of padding)
   for (int m = 0; m < cnt; m += 8) {
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = pm[2 * min(m + i, cnt - 1)];
+    for (int i = 0; i < 8; ++i) v[i] = pm[2 * (m + i)];
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc = acc + (m + i < cnt ? v[i] : 0.0f);
   }
   return acc;
 }
 
-template <int kRows, int kWR, bool kPair = false>
+template <int kRows, int kWR>
 __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
-  group_sync<kPair>();
+  __syncthreads();
   return forcing_phase2<kRows, kWR>(sm, res);
 }
 
@@ -588,16 +524,13 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
-// kPair: the group is one wavefront of a paired workgroup (see PairToken); `tok`
-// brackets its MFMA blocks.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kPair = false>
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
-                                          unsigned long long* trace = nullptr,
-                                          PairToken* tok = nullptr) {
-#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && group_tid<kPair>() == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+                                          unsigned long long* trace = nullptr) {
+#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && (int)threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
   constexpr bool kSpec = kEq >= 0;
@@ -617,17 +550,23 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 4;
   // specialised one-wave integrators keep loop invariants in registers
   constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0;
-  static_assert(!kPair || (kRows == 64 && kWR == 64), "paired groups are one-wave groups");
-  const int tid = opaque(group_tid<kPair>());
-  const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group_block<kPair>());
+  const int tid = opaque((int)threadIdx.x);
+  const Lane ln = make_lane<kRows, kWR>(p, batch, tid, (int)blockIdx.x);
   if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][kKW];
   if (!fixed) {
+    if (kKeepRows) {
 #pragma unroll
-    for (int t2 = 0; t2 < kWR / 32; ++t2)
-      tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int k = 0; k < kKW; ++k) hid_rows[t2][k] = res.hid_off[t2][k];
+    } else {
+#pragma unroll
+      for (int t2 = 0; t2 < kWR / 32; ++t2)
+        tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
+    }
   }
   const float un_reg = u / p.stddev;   // model.py:450-451, a true division
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
@@ -636,7 +575,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // previous evaluation (or the launch prologue), published here
   // (after the barrier: slower wavefronts may still be reading sm.fk in the
   // epilogue of the previous evaluation; the next barrier orders the readers)
-  group_sync<kPair>();
+  __syncthreads();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
   if (p.forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
     sm.fk[(unsigned)res.frc_run >> 24] = res.fk_next;
@@ -660,23 +599,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (!fixed) {
     DDD_STAMP(1);
     if (!(ablate & 16))
-      input_layer<kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act);
+      input_layer<kWR, kOneWave, kKeepRows>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act,
+                                            res.in_perm);
     const bool frc_next = p.forced && fast_forcing && !(ablate & 65);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
-      group_sync<kPair>();
-      if constexpr (kPair) {
-        // two token blocks per hidden layer (operand groups 0-9 and 10-19)
-        tok->acquire();
-        hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act,
-                          [tok]() { tok->release(); tok->acquire(); });
-        tok->release();
-      } else {
-        hidden_layer<kWR>(p, ln, in, out, res.hid, hid_rows, act);
-      }
+      __syncthreads();
+      hidden_layer<kWR, kKeepRows>(p, ln, in, out, res.hid, hid_rows, act);
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
@@ -702,14 +634,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       }
       // the hidden layer's last activations are on their way to LDS: fill the
       // wait with the forcing sums the next evaluation needs
-      if (nL == 2) group_sync<kPair>();   // no hidden layer: phase 1 -> phase 2 ordering
+      if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
       if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
-      group_sync<kPair>();
+      __syncthreads();
       f32x4 acc4[kNG];
       if (!(ablate & 4)) {
-        if constexpr (kPair) tok->acquire();
         final_layer4<kNG>(in, wf4, off4, acc4);
-        if constexpr (kPair) tok->release();
       } else {
 #pragma unroll
         for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -723,8 +653,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     }
   } else {
     if (p.forced && fast_forcing && !(ablate & 65))
-      res.fk_next = forcing_sums<kRows, kWR, kPair>(p, sm, res, t_next, tid);
-    group_sync<kPair>();   // all patch reads done before the next evaluation rewrites sm.u
+      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
+    __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
   }
 
   // ---- projection onto the accuracy-constrained stencils + stencil apply -----
@@ -841,7 +771,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
                                     : wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
       if (ln.owner) sm.flux[ln.row] = r;
-      group_sync<kPair>();
+      __syncthreads();
       fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     }
     r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
@@ -873,12 +803,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 }
 
 // Per-launch setup: resident registers and the per-sample tables in LDS.
-template <int kRows, int kWR, bool kHoist, bool kPair = false>
+template <int kRows, int kWR, bool kHoist>
 __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
                                              const Lane& ln, int batch, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
-  const int tid = group_tid<kPair>();
-  const int block = group_block<kPair>();
+  const int tid = (int)threadIdx.x;
+  const int block = (int)blockIdx.x;
   const int spg = kRows / p.N;
   for (int i = tid; i < kTabRows * kGMax; i += kThreads) {
     const int rowi = i / kGMax, g = i % kGMax;
@@ -904,6 +834,19 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
 #pragma unroll
         for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
           res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
+        const int half = ln.lane >> 5;
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          tap_rows<true>(ln, t2 * 32 + (ln.lane & 31), p.N, rows);
+#pragma unroll
+          for (int k = 0; k < kKW; ++k)
+            res.hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
+                                        64 * half);
+          // input layer: taps 0 / 1, taps 2 / 3, tap 4 (rows < 64 = lanes of this wavefront)
+          res.in_perm[t2][0] = opaque(4 * (half ? rows[1] : rows[0]));
+          res.in_perm[t2][1] = opaque(4 * (half ? rows[3] : rows[2]));
+          res.in_perm[t2][2] = opaque(4 * rows[4]);
+        }
       }
       const int gl = p.G >> 1;
 #pragma unroll
@@ -979,45 +922,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
 // kTrace: s_memtime phase stamps (DDD_TRACE_PTR, profiles/tools/trace_phases.py)
 // are compiled into the run-time-parameterised instantiation and into one
 // dedicated specialised instantiation only: their branches cost ~2 % otherwise.
-// kPair: eight token-paired one-wave groups per workgroup (PairToken), chosen by
-// the host when the batch gives every SIMD two wavefronts.
-template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0),
-          bool kPair = false>
-__global__ __launch_bounds__(kPair ? 64 * kPairWaves : kRows / kWR * 64, kPair ? 1 : 2)
-void integrate_kernel(DevParams p, IntegrateArgs a) {
-  __shared__ Shared<kRows, kWR> sms[kPair ? kPairWaves : 1];
-  __shared__ int pair_simd[kPairWaves];
-  __shared__ int pair_turn[kPairWaves];
-  Shared<kRows, kWR>& sm = sms[kPair ? (threadIdx.x >> 6) : 0];
-  PairToken tok{(lds_int*)pair_turn, 0, 0, 0ull, 0, 0, 0, (kPair && kTrace && a.trace != nullptr) ? 1 : 0};
-  const unsigned long long t_begin = (kPair && kTrace) ? __builtin_amdgcn_s_memtime() : 0ull;
-  int pair_info = 0;
-  if constexpr (kPair) {
-    // which two wavefronts of this workgroup share a SIMD?  (one workgroup
-    // fills its CU: LDS admits no second one, registers two wavefronts per SIMD)
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);   // HW_ID.simd_id
-    if ((threadIdx.x & 63) == 0) { pair_simd[w] = simd; pair_turn[w] = 0; }
-    __syncthreads();
-    int partner = -1, count = 0;
-#pragma unroll
-    for (int o = 0; o < kPairWaves; ++o)
-      if (pair_simd[o] == simd) { ++count; if (o != w) partner = o; }
-    // (all values below are wave-uniform: keep them in scalar registers)
-    count = __builtin_amdgcn_readfirstlane(count);
-    partner = __builtin_amdgcn_readfirstlane(partner);
-    pair_info = simd | (count << 4) | ((partner & 0xf) << 8) | (w << 12);
-    if (count == 2 && a.prio_split != 8) {   // prio_split = 8: A/B switch, groups free-run
-      tok.turn = (lds_int*)&pair_turn[w < partner ? w : partner];
-      tok.mine = w < partner ? 0 : 1;
-      tok.on = 1;
-      // the later wavefront starts one block behind: its first turn is empty
-      if (w > partner) { tok.acquire(); tok.release(); }
-    }
-  }
-  const Lane ln = make_lane<kRows, kWR>(p, a.batch, group_tid<kPair>(), group_block<kPair>());
+template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0)>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
+                                                                        IntegrateArgs a) {
+  __shared__ Shared<kRows, kWR> sm;
+  const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kWR, kHoist, kPair>(p, sm, ln, a.batch, res);
+  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
   // Two wavefronts share each SIMD and run the same phases; left alone they
   // phase-lock (both in their MFMA phase, then both in their VALU phase, the
   // matrix pipe idling).  A static priority split by hardware wave slot lets
@@ -1047,8 +958,8 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
   size_t snap = 0;
   int evals = 0;
   if (fast_frc && !(ablate & 1))
-    res.fk_next = forcing_sums<kRows, kWR, kPair>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
-                                                  group_tid<kPair>());
+    res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
+                                                  (int)threadIdx.x);
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
     ST ynew = y;
@@ -1057,17 +968,17 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
       unsigned long long* tr = nullptr;
-      if (kTrace && !kPair && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
-        tr = a.trace + (size_t)group_block<kPair>() * kTraceSlots + evals * 5;
+      if (kTrace && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
+        tr = a.trace + (size_t)(int)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
       // next step): its forcing sums are prepared inside this evaluation
       const double tn = s + 1 < a.tab.stages
                             ? t + a.tab.c[s + 1] * a.dt
                             : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
-      const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace, kPair>(
+      const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(
           p, sm, a.batch, (float)us, (float)(t + a.tab.c[s] * a.dt), (float)tn, res, fast_frc,
-          nullptr, nullptr, ablate, tr, &tok);
+          nullptr, nullptr, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
     }
@@ -1076,20 +987,6 @@ void integrate_kernel(DevParams p, IntegrateArgs a) {
       until_save = a.save_every;
       if (ln.active) y_out[snap * snap_stride + ln.gidx] = y;
       ++snap;
-    }
-  }
-  if constexpr (kPair) tok.finish();   // the partner runs its remaining blocks freely
-  if constexpr (kPair && kTrace) {
-    if (a.trace != nullptr && (threadIdx.x & 63) == 0) {
-      unsigned long long* tr = a.trace + (size_t)group_block<kPair>() * 8;
-      tr[0] = (unsigned long long)pair_info;
-      tr[1] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
-      tr[2] = tok.waited;
-      tr[3] = (unsigned long long)tok.polls;
-      tr[4] = (unsigned long long)tok.acquires;
-      tr[5] = (unsigned long long)tok.timeouts;
-      tr[6] = __builtin_amdgcn_s_memtime() - t_begin;
-      tr[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
     }
   }
 }
