@@ -15,6 +15,7 @@
 
 #include "../../include/ddd1d.h"
 #include "dev_params.h"
+#include "launch.h"
 #include "ops.h"
 #include "rhs_generic.h"
 #include "rhs_mfma.h"
@@ -516,15 +517,11 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
     // per-equation instantiations for the plain substep (no derivative views)
     const int eq = (a.derivs_out == nullptr && a.coeffs_out == nullptr && geo.wave_rows == 64)
                        ? spec_equation(m) : -1;
-#define DDD_SUBSTEP_CASE(EQ)                                                                \
-    case EQ:                                                                               \
-      if (geo.rows == 64)                                                                  \
-        hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64, EQ>), dim3(blocks), dim3(64), \
-                           0, stream, m->dp, a);                                           \
-      else                                                                                 \
-        hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64, EQ>), dim3(blocks),         \
-                           dim3(256), 0, stream, m->dp, a);                                \
-      break;
+    // specialised models: machine-sized grid, weights resident per wavefront,
+    // each group walks over several row groups (substep_multi_kernel)
+    const int grid = std::min(blocks, geo.rows == 64 ? 2 * device_simds() : device_simds() / 2);
+#define DDD_SUBSTEP_CASE(EQ) \
+    case EQ: ddd::launch::substep_spec<EQ>(geo.rows, m->dp, a, blocks, grid, stream); break;
     switch (eq) {
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS)
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS_CONS)
@@ -533,15 +530,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
       DDD_SUBSTEP_CASE(ddd::EQ_KS)
       DDD_SUBSTEP_CASE(ddd::EQ_KS_CONS)
       default:
-        if (geo.rows == 64 && geo.wave_rows == 64)
-          hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 64>), dim3(blocks), dim3(64), 0,
-                             stream, m->dp, a);
-        else if (geo.rows == 64)
-          hipLaunchKernelGGL((ddd::mfma::substep_kernel<64, 32>), dim3(blocks), dim3(128), 0,
-                             stream, m->dp, a);
-        else
-          hipLaunchKernelGGL((ddd::mfma::substep_kernel<256, 64>), dim3(blocks), dim3(256), 0,
-                             stream, m->dp, a);
+        ddd::launch::substep_runtime(geo.rows, geo.wave_rows, m->dp, a, blocks, stream);
     }
 #undef DDD_SUBSTEP_CASE
   } else {
@@ -563,43 +552,31 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   const int spg = kRows / m->dp.N;
   const int blocks = (a.batch + spg - 1) / spg;
   const bool hoist = !m->dp.fixed && m->dp.L == 3;
-  if constexpr (kWR == 64 && std::is_same<ST, float>::value) {
-    // float32 state on 64-row wavefronts: per-equation instantiations
-    const dim3 grid(blocks), block(kRows / kWR * 64);
-#define DDD_SPEC_CASE(EQ)                                                              \
-    case EQ:                                                                           \
-      hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true, EQ>), grid, \
-                         block, 0, stream, m->dp, a);                                  \
-      return;
-    int eq = spec_equation(m);
-    if (a.trace != nullptr) {
-      // phase tracing: the dedicated traced instantiation (headline config) or
-      // the run-time-parameterised kernel
-      if (eq == ddd::EQ_BURGERS_CONS && kRows == 64) {
-        hipLaunchKernelGGL((ddd::mfma::integrate_kernel<64, 64, float, true,
-                                                        ddd::EQ_BURGERS_CONS, true>),
-                           grid, block, 0, stream, m->dp, a);
-        return;
-      }
-      eq = -1;
-    }
-    switch (eq) {
-      DDD_SPEC_CASE(ddd::EQ_BURGERS)
-      DDD_SPEC_CASE(ddd::EQ_BURGERS_CONS)
-      DDD_SPEC_CASE(ddd::EQ_KDV)
-      DDD_SPEC_CASE(ddd::EQ_KDV_CONS)
-      DDD_SPEC_CASE(ddd::EQ_KS)
-      DDD_SPEC_CASE(ddd::EQ_KS_CONS)
-      default: break;
-    }
-#undef DDD_SPEC_CASE
+  constexpr bool f64 = std::is_same<ST, double>::value;
+  // per-equation instantiations exist for 64-row wavefronts: float32 state in
+  // both geometries, float64 state -- the SciPy-driven reference semantics,
+  // integrate.py:154 -- in the one-wave geometry (launch.h)
+  int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m) : -1;
+  bool traced = false;
+  if (a.trace != nullptr) {
+    // phase tracing: the dedicated traced instantiation (headline config) or
+    // the run-time-parameterised kernel
+    traced = eq == ddd::EQ_BURGERS_CONS && kRows == 64 && !f64;
+    if (!traced) eq = -1;
   }
-  if (hoist)
-    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, true>), dim3(blocks),
-                       dim3(kRows / kWR * 64), 0, stream, m->dp, a);
-  else
-    hipLaunchKernelGGL((ddd::mfma::integrate_kernel<kRows, kWR, ST, false>), dim3(blocks),
-                       dim3(kRows / kWR * 64), 0, stream, m->dp, a);
+#define DDD_SPEC_CASE(EQ) \
+  case EQ: ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); return;
+  switch (eq) {
+    DDD_SPEC_CASE(ddd::EQ_BURGERS)
+    DDD_SPEC_CASE(ddd::EQ_BURGERS_CONS)
+    DDD_SPEC_CASE(ddd::EQ_KDV)
+    DDD_SPEC_CASE(ddd::EQ_KDV_CONS)
+    DDD_SPEC_CASE(ddd::EQ_KS)
+    DDD_SPEC_CASE(ddd::EQ_KS_CONS)
+    default: break;
+  }
+#undef DDD_SPEC_CASE
+  ddd::launch::integrate_runtime(kRows, kWR, f64, hoist, m->dp, a, blocks, stream);
 }
 
 template <typename ST>

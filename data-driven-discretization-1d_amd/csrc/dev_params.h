@@ -225,6 +225,16 @@ __device__ __forceinline__ float equation_rhs_or_flux(int eq, float y,
   }
 }
 
+namespace ops {
+// DPP wavefront rotate: out[l] = in[(l + 1) % 64] if `wave_rol:1` does what the
+// flux exchange of the one-wave kernel assumes (checked on the device at first
+// use: ops.h dpp_rotate_probe_kernel, capi.hip dpp_wave_rol_ok).
+__device__ __forceinline__ float wave_rotate_left1(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /* wave_rol:1 */,
+                                                    0xf, 0xf, false));
+}
+}  // namespace ops
+
 // Forcing of one sample at one grid point: sum_j a sin((omega t + sp) + phi),
 // float32 in the TF graph's order (equations.py:214-219).
 __device__ __forceinline__ float forcing_at(const DevParams& p, const float4* frc,

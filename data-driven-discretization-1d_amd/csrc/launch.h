@@ -1,0 +1,81 @@
+// Launch entry points of the MFMA kernels, one translation unit per equation
+// so that the library builds in parallel (each per-equation specialisation of
+// the integrator is ~3 k lines of ISA; a single unit took minutes):
+//   mfma_spec.hip   compiled once per equation id (-DDDD_EQ=0..5): the
+//                   specialised persistent integrators (float32 state in both
+//                   geometries, float64 state in the one-wave geometry, the
+//                   traced instantiation) and the multi-group substep kernels
+//   mfma_runtime.hip  the run-time-parameterised kernels (kEq = -1), once per
+//                     (geometry, state type)
+//   capi.hip          C ABI, packing, every other kernel
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_params.h"
+
+namespace ddd {
+namespace launch {
+
+// rows: 64 (one-wave groups) or 256; f64: float64 state (rows = 64 only);
+// traced: the s_memtime-stamped instantiation (Burgers flux form, rows 64, f32).
+template <int kEq>
+void integrate_spec(int rows, bool f64, bool traced, const DevParams& p, const IntegrateArgs& a,
+                    int blocks, hipStream_t stream);
+// grid: workgroups to launch (<= groups); every workgroup walks over groups.
+template <int kEq>
+void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
+                  hipStream_t stream);
+
+#define DDD_DECLARE_SPEC(EQ)                                                               \
+  template <> void integrate_spec<EQ>(int, bool, bool, const DevParams&, const IntegrateArgs&, \
+                                      int, hipStream_t);                                       \
+  template <> void substep_spec<EQ>(int, const DevParams&, const SubstepArgs&, int, int,       \
+                                    hipStream_t);
+DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
+DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
+#undef DDD_DECLARE_SPEC
+
+// run-time-parameterised kernels, one unit per (rows, wave_rows, float64 state):
+// (64, 64), (64, 32) -- the same 64 rows on two wavefronts -- and (256, 64)
+template <int kRows, int kWR, int kF64>
+void integrate_runtime_unit(bool hoist, const DevParams& p, const IntegrateArgs& a, int blocks,
+                            hipStream_t stream);
+template <int kRows, int kWR>
+void substep_runtime_unit(const DevParams& p, const SubstepArgs& a, int blocks,
+                          hipStream_t stream);
+
+#define DDD_DECLARE_RT(ROWS, WR)                                                              \
+  template <> void integrate_runtime_unit<ROWS, WR, 0>(bool, const DevParams&,               \
+                                                       const IntegrateArgs&, int, hipStream_t); \
+  template <> void integrate_runtime_unit<ROWS, WR, 1>(bool, const DevParams&,               \
+                                                       const IntegrateArgs&, int, hipStream_t); \
+  template <> void substep_runtime_unit<ROWS, WR>(const DevParams&, const SubstepArgs&, int, \
+                                                  hipStream_t);
+DDD_DECLARE_RT(64, 64)
+DDD_DECLARE_RT(64, 32)
+DDD_DECLARE_RT(256, 64)
+#undef DDD_DECLARE_RT
+
+inline void integrate_runtime(int rows, int wave_rows, bool f64, bool hoist, const DevParams& p,
+                              const IntegrateArgs& a, int blocks, hipStream_t stream) {
+  if (rows == 64 && wave_rows == 64) {
+    if (f64) integrate_runtime_unit<64, 64, 1>(hoist, p, a, blocks, stream);
+    else integrate_runtime_unit<64, 64, 0>(hoist, p, a, blocks, stream);
+  } else if (rows == 64) {
+    if (f64) integrate_runtime_unit<64, 32, 1>(hoist, p, a, blocks, stream);
+    else integrate_runtime_unit<64, 32, 0>(hoist, p, a, blocks, stream);
+  } else {
+    if (f64) integrate_runtime_unit<256, 64, 1>(hoist, p, a, blocks, stream);
+    else integrate_runtime_unit<256, 64, 0>(hoist, p, a, blocks, stream);
+  }
+}
+
+inline void substep_runtime(int rows, int wave_rows, const DevParams& p, const SubstepArgs& a,
+                            int blocks, hipStream_t stream) {
+  if (rows == 64 && wave_rows == 64) substep_runtime_unit<64, 64>(p, a, blocks, stream);
+  else if (rows == 64) substep_runtime_unit<64, 32>(p, a, blocks, stream);
+  else substep_runtime_unit<256, 64>(p, a, blocks, stream);
+}
+
+}  // namespace launch
+}  // namespace ddd

@@ -1,0 +1,53 @@
+// Per-equation specialised MFMA kernels: this file is compiled once per
+// equation id (-DDDD_EQ=<0..5>, __graft_entry__.build_hip); see launch.h.
+#include <hip/hip_runtime.h>
+
+#include "launch.h"
+#include "rhs_mfma.h"
+
+#ifndef DDD_EQ
+#error "compile with -DDDD_EQ=<equation id 0..5>"
+#endif
+
+namespace ddd {
+namespace launch {
+
+template <>
+void integrate_spec<DDD_EQ>(int rows, bool f64, bool traced, const DevParams& p,
+                            const IntegrateArgs& a, int blocks, hipStream_t stream) {
+  const dim3 grid(blocks);
+  if (rows == 64) {
+    if (f64) {
+      hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, double, true, DDD_EQ>), grid, dim3(64),
+                         0, stream, p, a);
+      return;
+    }
+#if DDD_EQ == 1   // EQ_BURGERS_CONS: the headline configuration carries the phase stamps
+    if (traced) {
+      hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ, true>), grid,
+                         dim3(64), 0, stream, p, a);
+      return;
+    }
+#endif
+    (void)traced;
+    hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ>), grid, dim3(64), 0,
+                       stream, p, a);
+  } else {
+    hipLaunchKernelGGL((mfma::integrate_kernel<256, 64, float, true, DDD_EQ>), grid, dim3(256),
+                       0, stream, p, a);
+  }
+}
+
+template <>
+void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, int groups,
+                          int grid, hipStream_t stream) {
+  if (rows == 64)
+    hipLaunchKernelGGL((mfma::substep_multi_kernel<64, 64, DDD_EQ>), dim3(grid), dim3(64), 0,
+                       stream, p, a, groups);
+  else
+    hipLaunchKernelGGL((mfma::substep_multi_kernel<256, 64, DDD_EQ>), dim3(grid), dim3(256), 0,
+                       stream, p, a, groups);
+}
+
+}  // namespace launch
+}  // namespace ddd

@@ -144,13 +144,6 @@ __global__ void apply_space_derivatives_kernel(const float* __restrict__ derivs,
   }
 }
 
-// DPP wavefront rotate: out[l] = in[(l + 1) % 64] if `wave_rol:1` does what the
-// flux exchange of the one-wave kernel assumes.
-__device__ __forceinline__ float wave_rotate_left1(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x134 /* wave_rol:1 */,
-                                                    0xf, 0xf, false));
-}
-
 __global__ void dpp_rotate_probe_kernel(float* __restrict__ out) {
   out[threadIdx.x] = wave_rotate_left1((float)(threadIdx.x * 3 + 1));
 }

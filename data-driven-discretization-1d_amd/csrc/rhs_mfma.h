@@ -529,7 +529,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, int ablate = 0,
-                                          unsigned long long* trace = nullptr) {
+                                          unsigned long long* trace = nullptr,
+                                          int group = -1) {
 #define DDD_STAMP(i) do { if (kTrace && trace != nullptr && (int)threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
@@ -551,7 +552,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // specialised one-wave integrators keep loop invariants in registers
   constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0;
   const int tid = opaque((int)threadIdx.x);
-  const Lane ln = make_lane<kRows, kWR>(p, batch, tid, (int)blockIdx.x);
+  const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
   if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
@@ -802,6 +803,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   return r;
 }
 
+template <int kRows, int kWR>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR>& sm,
+                                              int block, int batch, Resident& res, bool fast);
+
 // Per-launch setup: resident registers and the per-sample tables in LDS.
 template <int kRows, int kWR, bool kHoist>
 __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
@@ -854,8 +859,6 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
         res.pch_idx[g] = opaque(((ln.pos + g - gl) & (p.N - 1)) | ln.base);
     }
   }
-  res.frc_a = res.frc_omega = res.frc_phi = 0.0f;
-  res.fk_next = 0.0f;
   if (fast && p.n_k <= 4 && ln.owner) {
     // cos/sin of this grid point's spatial phases -> the row padding
     const float4* __restrict__ tr =
@@ -863,29 +866,63 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
     *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = tr[0];
     *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = tr[1];
   }
-  for (int i = tid; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
+  setup_samples<kRows, kWR>(p, sm, block, batch, res, fast);
+  return fast;
+}
+
+// The part of the setup that belongs to the group's SAMPLES (their forcing
+// parameters and mode runs): once per launch in the persistent integrators,
+// once per group in the multi-group substep kernel, which fetches the next
+// group's values (fetch_samples) while the current group is being evaluated.
+struct SampleSetup {
+  float a, omega, phi;   // this lane's (sample, mode) forcing parameters
+  int run;               // Resident::frc_run
+};
+
+template <int kRows, int kWR>
+__device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int block, int batch,
+                                                     bool fast) {
+  const int tid = (int)threadIdx.x;
+  const int spg = kRows / p.N;
+  SampleSetup s{0.0f, 0.0f, 0.0f, 0};
   if (fast && tid < spg * p.P) {
     const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
     const long sample = (long)block * spg + fsl;
     if (sample < batch) {
       const float4 q = p.frc[sample * p.P + (tid - fsl * p.P)];
-      res.frc_a = q.x; res.frc_omega = q.y; res.frc_phi = q.z;
+      s.a = q.x; s.omega = q.y; s.phi = q.z;
     }
   }
   // this lane's run of modes [m0, m1): runs[sample][kk] = first (sorted) mode of
   // the sample whose k index is >= kk, precomputed by ddd_set_forcing
-  res.frc_run = 0;
   if (fast && tid < spg * p.n_k * 2) {
     const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
     const int kk = (tid >> 1) - sl * p.n_k;
     const long sample = (long)block * spg + sl;
     if (sample < batch) {
       const int m0 = p.runs[sample * 8 + kk], m1 = p.runs[sample * 8 + kk + 1];
-      res.frc_run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
-                    ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
+      s.run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
+              ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
     }
   }
-  return fast;
+  return s;
+}
+
+template <int kRows, int kWR>
+__device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& res,
+                                              const SampleSetup& s) {
+  constexpr int kThreads = kRows / kWR * 64;
+  res.frc_a = s.a; res.frc_omega = s.omega; res.frc_phi = s.phi;
+  res.frc_run = s.run;
+  res.fk_next = 0.0f;
+  for (int i = (int)threadIdx.x; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
+}
+
+template <int kRows, int kWR>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR>& sm,
+                                              int block, int batch, Resident& res,
+                                              bool fast) {
+  apply_samples<kRows, kWR>(sm, res, fetch_samples<kRows, kWR>(p, block, batch, fast));
 }
 
 // ---------------------------------------------------------------------------
@@ -911,6 +948,55 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
   if (a.acc_out != nullptr) {
     const float cf = a.c2 * f;
     a.acc_out[ln.gidx] = a.acc_in != nullptr ? a.acc_in[ln.gidx] + cf : cf;
+  }
+}
+
+// Kernel 1b: the same fused substep for the per-equation specialised models,
+// built like the persistent integrator: the grid is sized to the machine (two
+// wavefronts per SIMD), every group keeps the conv weights and operand offsets
+// resident and walks over `groups / gridDim.x` row groups.  A launch per group
+// (kernel 1) makes every wavefront fetch its 29 KB of weights again -- 120 MB of
+// L2 traffic per substep at batch 4096 -- and pays a second dispatch round.
+template <int kRows, int kWR, int kEq>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevParams p,
+                                                                            SubstepArgs a,
+                                                                            int groups) {
+  __shared__ Shared<kRows, kWR> sm;
+  Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
+  Resident res;
+  const bool fast_frc = launch_setup<kRows, kWR, true>(p, sm, ln, a.batch, res);
+  float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    // the next group's state and forcing rows: in flight during this evaluation
+    const int nxt = grp + (int)gridDim.x;
+    Lane ln_next = ln;
+    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0};
+    float u_next = 0.0f;
+    if (nxt < groups) {
+      ln_next = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, nxt);
+      u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
+      s_next = fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc);
+    }
+    // the update's other operands: requested now, consumed after the evaluation
+    const float base = (ln.active && a.y_out != nullptr && a.y_base != nullptr)
+                           ? a.y_base[ln.gidx] : 0.0f;
+    const float acc_in = (ln.active && a.acc_out != nullptr && a.acc_in != nullptr)
+                             ? a.acc_in[ln.gidx] : 0.0f;
+    if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
+    const float f = eval_rhs<kRows, kWR, true, kEq, false>(p, sm, a.batch, u, (float)a.t,
+                                                           (float)a.t, res, fast_frc, nullptr,
+                                                           nullptr, 64, nullptr, grp);
+    if (ln.active) {
+      // (x + c f with x = 0 when there is no base array: the same bits as c f)
+      if (a.y_out != nullptr) a.y_out[ln.gidx] = base + a.c1 * f;
+      if (a.acc_out != nullptr) a.acc_out[ln.gidx] = acc_in + a.c2 * f;
+    }
+    if (nxt < groups) {
+      __syncthreads();   // this group's epilogue has read sm.fk / sm.u
+      ln = ln_next;
+      u = u_next;
+      apply_samples<kRows, kWR>(sm, res, s_next);
+    }
   }
 }
 

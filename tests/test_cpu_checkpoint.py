@@ -158,3 +158,93 @@ def test_model_loads_from_reference_style_checkpoint_dir(tmp_path):
   checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt'), tensors)
   with pytest.raises(KeyError, match='conv1d_2/kernel'):
     model_lib.LearnedStencilModel.load(str(tmp_path))
+
+
+# ---------------------------------------------------------------------------
+# bytes this package's writer did not produce (tests/golden/tf_checkpoint,
+# assembled from the public format definitions by make_tf_checkpoint_fixture.py)
+# ---------------------------------------------------------------------------
+FIXTURE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'tf_checkpoint')
+
+
+def test_reader_on_hand_assembled_bundle():
+  tensors = checkpoint.read_checkpoint(os.path.join(FIXTURE_DIR, 'model.ckpt'))
+  expected = np.load(os.path.join(FIXTURE_DIR, 'expected.npz'))
+  assert len(expected.files) == 6
+  for key in expected.files:
+    name = key.replace('__', '/')
+    assert tensors[name].dtype == np.float32
+    np.testing.assert_array_equal(tensors[name], expected[key])
+  # training leftovers are read faithfully and ignored by the model loader
+  assert tensors['global_step'] == 40000 and tensors['global_step'].dtype == np.int64
+  assert abs(float(tensors['beta1_power']) - 0.729) < 1e-6
+  assert tensors['predict_coefficients/conv1d_1/kernel/Adam_1'].shape == (5, 32, 32)
+  hp = ddd1d_amd.load_hparams(FIXTURE_DIR)
+  assert (hp.equation, hp.conservative, hp.num_layers, hp.resample_factor) == (
+      'burgers', True, 3, 8)
+  assert hp.learning_rates == [0.001, 0.0001] and hp.learning_stops == [20000, 40000]
+  model = model_lib.LearnedStencilModel.load(FIXTURE_DIR)
+  assert type(model.equation).__name__ == 'ConservativeBurgersEquation'
+  assert model.equation.grid.solution_num_points == 64
+  for layer, suffix in enumerate(('', '_1', '_2')):
+    np.testing.assert_array_equal(
+        model.conv_kernels[layer],
+        expected['predict_coefficients__conv1d{}__kernel'.format(suffix)])
+    np.testing.assert_array_equal(
+        model.conv_biases[layer],
+        expected['predict_coefficients__conv1d{}__bias'.format(suffix)])
+
+
+@pytest.mark.parametrize('target', ['coefficients', 'space_derivatives',
+                                    'time_derivative', 'flux'])
+def test_variable_scope_follows_model_target(tmp_path, target):
+  """Only predict_coefficients opens the 'predict_coefficients' variable scope
+  (model.py:442); the direct heads are built by _multilayer_conv1d without one
+  (model.py:551-569) -> plain conv1d/kernel ...  (ADVICE r1)."""
+  conservative = target != 'time_derivative'
+  hp = ddd1d_amd.create_hparams('burgers', conservative=conservative, resample_factor=8,
+                                equation_kwargs='{"num_points": 512}', model_target=target)
+  _, eq = equations.from_hparams(hp)
+  if target == 'flux' and not eq.CONSERVATIVE:
+    pytest.skip('flux head needs a conservative equation')
+  model = model_lib.LearnedStencilModel(eq, hp, init_seed=5)
+  names = checkpoint.conv_variable_names(hp.num_layers, target)
+  prefix = 'predict_coefficients/' if target == 'coefficients' else ''
+  assert names[0] == (prefix + 'conv1d/kernel', prefix + 'conv1d/bias')
+  assert names[2] == (prefix + 'conv1d_2/kernel', prefix + 'conv1d_2/bias')
+  tensors = {}
+  for (kname, bname), w, b in zip(names, model.conv_kernels, model.conv_biases):
+    tensors[kname], tensors[bname] = w, b
+  (tmp_path / 'hparams.pbtxt').write_text(checkpoint.format_hparams_pbtxt(hp.values()))
+  checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt'), tensors)
+  restored = model_lib.LearnedStencilModel.load(str(tmp_path))
+  assert restored.hparams.model_target == target
+  for a, b in zip(restored.conv_kernels, model.conv_kernels):
+    np.testing.assert_array_equal(a, b)
+  # the other scope is NOT accepted silently
+  wrong = {('predict_coefficients/' + k if not prefix else k[len(prefix):]): v
+           for k, v in tensors.items()}
+  checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt'), wrong)
+  with pytest.raises(KeyError, match='conv1d/kernel'):
+    model_lib.LearnedStencilModel.load(str(tmp_path))
+
+
+def test_num_layers_zero_checkpoint_restores_the_learned_constants(tmp_path):
+  """num_layers = 0: the trained vector is predict_coefficients/coefficients
+  (model.py:496-499); it must not be dropped."""
+  hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8,
+                                equation_kwargs='{"num_points": 512}', num_layers=0)
+  _, eq = equations.from_hparams(hp)
+  probe = model_lib.LearnedStencilModel(eq, hp)
+  count = probe.num_outputs
+  learned = np.arange(1, count + 1, dtype=np.float32)
+  (tmp_path / 'hparams.pbtxt').write_text(checkpoint.format_hparams_pbtxt(hp.values()))
+  checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt'),
+                              {'predict_coefficients/coefficients': learned,
+                               'global_step': np.array(1, np.int64)})
+  restored = model_lib.LearnedStencilModel.load(str(tmp_path))
+  np.testing.assert_array_equal(restored.constant_coefficients, learned)
+  checkpoint.write_checkpoint(str(tmp_path / 'model.ckpt'),
+                              {'global_step': np.array(1, np.int64)})
+  with pytest.raises(KeyError, match='predict_coefficients/coefficients'):
+    model_lib.LearnedStencilModel.load(str(tmp_path))

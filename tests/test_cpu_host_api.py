@@ -132,6 +132,28 @@ def test_forcing_tables_shapes():
                            k=np.zeros((2, 4)), phi=np.zeros((2, 3))))
 
 
+def test_forcing_tables_with_zero_wavenumber():
+  """equation_kwargs k_min = 0 draws constant modes (k = 0): the Dirichlet
+  factor of the block mean is 1 there, not 0/0.  The folded tables
+  must reproduce the reference-grid evaluation (oracle.forcing_f32)."""
+  import oracle
+  eq = equations.ConservativeBurgersEquation(32, resample_factor=4, k_min=0, k_max=2,
+                                             random_seed=4)
+  forcing = model_lib.forcing_from_equations([eq])
+  assert (forcing['k'] == 0).any()
+  tab = model_lib.forcing_kernel_tables(forcing, eq.grid)
+  for key in ('amplitude', 'phase', 'spatial_phase'):
+    assert np.isfinite(tab[key]).all(), key
+  t = 0.37
+  phase = (tab['omega'][..., None] * np.float32(t)
+           + tab['spatial_phase'][tab['k_index']] + tab['phase'][..., None])
+  got = np.sum(tab['amplitude'][..., None] * np.sin(phase.astype(np.float64)), axis=1)
+  want = oracle.forcing_f32(t, forcing, 32, 4, eq.grid.period, True)
+  np.testing.assert_allclose(got, want, atol=2e-6)
+  # and it is what the host equation computes (RandomForcing + Grid.resample)
+  np.testing.assert_allclose(got[0], eq.forcing(t), atol=2e-6)
+
+
 def test_shard_bounds():
   for total, world in [(65536, 8), (10, 3), (7, 8), (0, 4)]:
     covered = []
