@@ -464,9 +464,17 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
 // Equation id of the compile-time specialised integrator this model can use,
 // or -1: the default architecture (three relu conv layers, default stencil
 // width, projection folded when D <= 2) on a non-Godunov equation.
-int spec_equation(const ddd_model* m) {
+int spec_equation(const ddd_model* m, int rows) {
   const ddd::DevParams& dp = m->dp;
   if (g_debug.no_spec) return -1;
+  if (dp.forced) {
+    // the specialised kernels only carry the harmonic-sum forcing (rhs_mfma.h:
+    // launch_setup `fast`); exotic tables go to the run-time kernels
+    const int spg = rows / dp.N;
+    const bool fast = spg * dp.P <= rows && dp.n_k <= 6 &&
+                      spg * ddd::mfma::kTrigMax <= 3 * rows / 4 && dp.P < 256;
+    if (!fast) return -1;
+  }
   if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
   if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
   if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
@@ -516,7 +524,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
     const int blocks = (a.batch + spg - 1) / spg;
     // per-equation instantiations for the plain substep (no derivative views)
     const int eq = (a.derivs_out == nullptr && a.coeffs_out == nullptr && geo.wave_rows == 64)
-                       ? spec_equation(m) : -1;
+                       ? spec_equation(m, geo.rows) : -1;
     // specialised models: machine-sized grid, weights resident per wavefront,
     // each group walks over several row groups (substep_multi_kernel)
     const int grid = std::min(blocks, geo.rows == 64 ? 2 * device_simds() : device_simds() / 2);
@@ -556,7 +564,7 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   // per-equation instantiations exist for 64-row wavefronts: float32 state in
   // both geometries, float64 state -- the SciPy-driven reference semantics,
   // integrate.py:154 -- in the one-wave geometry (launch.h)
-  int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m) : -1;
+  int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m, kRows) : -1;
   bool traced = false;
   if (a.trace != nullptr) {
     // phase tracing: the dedicated traced instantiation (headline config) or

@@ -89,6 +89,11 @@ __host__ __device__ constexpr bool spec_flux_form(int eq) {
   return eq == EQ_BURGERS_CONS || eq == EQ_KDV_CONS || eq == EQ_KS_CONS;
 }
 __host__ __device__ constexpr int spec_stencil(int eq) { return spec_flux_form(eq) ? 6 : 7; }
+// Only Burgers adds forcing(t) in finalize_time_derivative (equations.py:276-277):
+// the other specialised kernels carry no forcing code at all.
+__host__ __device__ constexpr bool spec_forced_family(int eq) {
+  return eq == EQ_BURGERS || eq == EQ_BURGERS_CONS;
+}
 // Output channels of the specialised kernels' last layer, in groups of four
 // (final_layer4): D <= 2: the folded layer emits the D x G stencil coefficients
 // (12 or 14 channels); D = 3 (KS): the 5 + 4 + 2 null-space coordinates.
@@ -461,6 +466,7 @@ struct Resident {
   int fin4_off[kKW];        // LDS byte offsets of this lane's five tap rows (same kernels)
   int hid_off[2][kKW];      // LDS byte offsets of the hidden layer's operand rows (same kernels)
   int in_perm[2][3];        // ds_bpermute addresses of the input layer's operands (same kernels)
+  float4 trig[kTrigMax / 4];   // this grid point's cos / sin of the spatial phases (same kernels)
   int pch_idx[kGMax];       // indices into Shared::u of this row's stencil patch (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
@@ -542,6 +548,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const bool fixed = kSpec ? false : (p.fixed != 0);
   const bool folded = kSpec ? (spec_derivs(kEq) <= 2) : (p.folded != 0);
   const int act = kSpec ? (int)ACT_RELU : p.act;
+  // specialised kernels: forcing only in the Burgers family, and only in its
+  // harmonic-sum form (capi.hip routes anything else to the run-time kernels)
+  const bool forced = kSpec ? (spec_forced_family(kSpec ? kEq : 0) && p.forced != 0)
+                            : (p.forced != 0);
+  if (kSpec) fast_forcing = true;
   const int nL = kHoist ? 3 : p.L;
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
@@ -578,7 +589,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // epilogue of the previous evaluation; the next barrier orders the readers)
   __syncthreads();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
-  if (p.forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
+  if (forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
     sm.fk[(unsigned)res.frc_run >> 24] = res.fk_next;
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
@@ -602,7 +613,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     if (!(ablate & 16))
       input_layer<kWR, kOneWave, kKeepRows>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act,
                                             res.in_perm);
-    const bool frc_next = p.forced && fast_forcing && !(ablate & 65);
+    const bool frc_next = forced && fast_forcing && !(ablate & 65);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     float* in = sm.hA;
     float* out = sm.hB;
@@ -653,7 +664,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
         for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
     }
   } else {
-    if (p.forced && fast_forcing && !(ablate & 65))
+    if (forced && fast_forcing && !(ablate & 65))
       res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
     __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
   }
@@ -668,8 +679,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // this grid point's cos / sin of the spatial phases: issued at the top of
   // the epilogue, consumed by its last statement
   float4 trig4[kTrigMax / 4];
-  if (p.forced && fast_forcing) {
-    if (trig_lds) {
+  if (forced && fast_forcing) {
+    if (kKeepRows) {
+      // resident for the launch: lane == grid point never changes
+#pragma unroll
+      for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = res.trig[i];
+    } else if (trig_lds) {
       // <= 4 wavenumbers: the table sits in the four padding floats of this
       // row in each activation buffer (launch_setup), never overwritten
       trig4[0] = *reinterpret_cast<const float4*>(sm.hA + ln.row * kHS + 32);
@@ -777,8 +792,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     }
     r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
   }
-  if (p.forced && !(ablate & 1)) {
-    if (fast_forcing) {
+  if (forced && !(ablate & 1)) {
+    if (kSpec || fast_forcing) {
       // phase 3: combine with this grid point's cos / sin table (both zero
       // padded to 12 entries: no branches)
       const float4* __restrict__ fk4 =
@@ -786,7 +801,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
-        if (i == 2 && trig_lds) break;   // entries 8..11 are zero padding
+        if (i == 2 && trig_lds && !kKeepRows) break;   // entries 8..11 are zero padding
         const float4 f = fk4[i];
         total = fmaf(f.x, trig4[i].x, total);
         total = fmaf(f.y, trig4[i].y, total);
@@ -858,6 +873,14 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
       for (int g = 0; g < kGMax; ++g)
         res.pch_idx[g] = opaque(((ln.pos + g - gl) & (p.N - 1)) | ln.base);
     }
+  }
+#pragma unroll
+  for (int i = 0; i < kTrigMax / 4; ++i) res.trig[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (fast && kHoist && kRows == 64 && kWR == 64) {
+    const float4* __restrict__ tr =
+        reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
+#pragma unroll
+    for (int i = 0; i < kTrigMax / 4; ++i) res.trig[i] = tr[i];
   }
   if (fast && p.n_k <= 4 && ln.owner) {
     // cos/sin of this grid point's spatial phases -> the row padding
@@ -1035,6 +1058,10 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
   }
+  // traced instantiation: shader-clock ticks (s_memtime) against the constant
+  // 100 MHz counter (s_memrealtime) over the whole launch -> effective clock
+  const unsigned long long clk0 = kTrace ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long real0 = kTrace ? __builtin_amdgcn_s_memrealtime() : 0ull;
   const ST* y0 = static_cast<const ST*>(a.y0);
   ST* y_out = static_cast<ST*>(a.y_out);
   ST y = ln.valid ? y0[ln.gidx] : (ST)0;   // both half-waves carry the state
@@ -1074,6 +1101,11 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       if (ln.active) y_out[snap * snap_stride + ln.gidx] = y;
       ++snap;
     }
+  }
+  if (kTrace && a.trace != nullptr && threadIdx.x == 0) {
+    unsigned long long* tr = a.trace + (size_t)blockIdx.x * kTraceSlots;
+    tr[kTraceSlots - 2] = __builtin_amdgcn_s_memtime() - clk0;
+    tr[kTraceSlots - 1] = __builtin_amdgcn_s_memrealtime() - real0;
   }
 }
 

@@ -10,8 +10,18 @@ m.set_forcing(model_lib.batched_forcing_parameters(range(B), nparams=20))
 y0 = torch.randn(B, 64, device='cuda') * 0.3
 trace = torch.zeros(B * 256, dtype=torch.int64, device='cuda')
 ddd1d_amd._lib.debug_set_option('trace_ptr', trace.data_ptr())
-m.integrate_fixed(y0, 25, dt=1e-3, save_every=25)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+m.integrate_fixed(y0, 2000, dt=1e-3, save_every=2000)   # warm: clocks settled
 torch.cuda.synchronize()
+raw = trace.cpu().numpy().reshape(B, 256)
+ticks, real = raw[:, 254].astype(np.float64), raw[:, 255].astype(np.float64)
+print('2000-step launch per wave: s_memtime ticks mean %.0f, s_memrealtime (100 MHz) ticks mean %.0f -> s_memtime rate %.1f MHz' % (ticks.mean(), real.mean(), 100.0 * ticks.mean() / real.mean()))
+trace.zero_()
+m.integrate_fixed(y0, steps, dt=1e-3, save_every=steps)
+torch.cuda.synchronize()
+raw = trace.cpu().numpy().reshape(B, 256)
+ticks, real = raw[:, 254].astype(np.float64), raw[:, 255].astype(np.float64)
+print('whole launch per wave: s_memtime ticks mean %.0f, s_memrealtime (100 MHz) ticks mean %.0f -> s_memtime rate %.1f MHz' % (ticks.mean(), real.mean(), 100.0 * ticks.mean() / real.mean()))
 tr = trace.cpu().numpy().reshape(B, 256)[:, :250].reshape(B, 50, 5)
 # co-resident pairs (from the placement probe): block b and b + 768 (first round)
 for b in (0, 1, 8):
