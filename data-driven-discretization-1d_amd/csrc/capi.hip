@@ -152,6 +152,7 @@ struct ddd_model {
   int kernel = DDD_KERNEL_GENERIC;   // resolved family
   int force_rows = 0;                // 0 = automatic; 64 / 32 (64 rows on two waves) / 256
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
+  bool spec_folded = false;          // w_final4 (specialised kernels) holds the folded output layer
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
   const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
@@ -282,19 +283,15 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     const int l = dp.L - 1;
     const float* w_nat = weights + dp.w_off[l];   // [5][32][C_out]
     const float* b_nat = weights + dp.b_off[l];
-    int cout_n = dp.C_out;
+    // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
+    // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
+    // (accumulated in double, rounded once to float32), same for the bias.
+    // The layer then emits the D x 8 coefficient deltas directly and the
+    // epilogue's projection disappears.  Deviation from the reference's
+    // operation order: O(1 ulp) of the deltas, far inside the 1e-5 tolerance.
     std::vector<float> wf, bf;
-    const float* w = w_nat;
-    const float* b = b_nat;
-    m->dp.folded = 0;
-    if (dp.D <= 2 && !g_debug.no_fold) {
-      // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
-      // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
-      // (accumulated in double, rounded once to float32), same for the bias.
-      // The layer then emits the D x 8 coefficient deltas directly and the
-      // epilogue's projection disappears.  Deviation from the reference's
-      // operation order: O(1 ulp) of the deltas, far inside the 1e-5 tolerance.
-      cout_n = 16;
+    const bool can_fold = dp.D <= 2 && !g_debug.no_fold;
+    if (can_fold) {
       wf.assign((size_t)5 * 32 * 16, 0.0f);
       bf.assign(16, 0.0f);
       for (int d = 0; d < dp.D; ++d)
@@ -314,20 +311,18 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
             acc += (double)b_nat[dp.in_start[d] + j] * (double)dp.ns8[dp.in_start[d] + j][g];
           bf[oc] = (float)acc;
         }
-      w = wf.data();
-      b = bf.data();
-      m->dp.folded = 1;
     }
     // Packing for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4): channels
     // grouped by four; instruction q = k * groups + grp reads lanes
     // 4 (q % 16) .. + 3 of weight register q / 16, lane 4 abid + r carrying
     // channel 4 grp + r; k = (tap, cin) in natural order, k = 160: bias.
-    //   w_final4    : live channels renumbered contiguously (folded: G d + g),
-    //                 ceil(n / 4) groups -- the per-equation specialised kernels
-    //   w_final4_pad: the 16 channels as they are (folded: 8 d + g), 4 groups --
-    //                 the run-time-parameterised kernels
-    const int n_ch = m->dp.folded ? dp.D * dp.G : dp.C_out;
-    auto pack4 = [&](int groups, bool renumber) {
+    // `folded`: source = the folded layer (16 channels, 8 d + g), else the
+    // natural one; `renumber`: live channels made contiguous (folded: G d + g).
+    auto pack4 = [&](int groups, bool folded, bool renumber) {
+      const float* w = folded ? wf.data() : w_nat;
+      const float* b = folded ? bf.data() : b_nat;
+      const int cout_n = folded ? 16 : dp.C_out;
+      const int n_ch = folded ? dp.D * dp.G : dp.C_out;
       std::vector<float> packed4((size_t)ddd::mfma::fin4_regs(4) * 64, 0.0f);
       for (int k = 0; k < ddd::mfma::kFin4K; ++k)
         for (int grp = 0; grp < groups; ++grp) {
@@ -337,7 +332,7 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
             int src = ch;
             if (renumber) {
               if (ch >= n_ch) continue;
-              src = m->dp.folded ? 8 * (ch / dp.G) + ch % dp.G : ch;
+              src = folded ? 8 * (ch / dp.G) + ch % dp.G : ch;
             }
             if (src >= cout_n) continue;
             packed4[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
@@ -346,13 +341,19 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
         }
       return packed4;
     };
-    m->dp.fin4_groups = (n_ch + 3) / 4;
-    int rc = upload(pack4(m->dp.fin4_groups, true), &m->d_w_final4);
-    if (rc) return rc;
-    m->dp.w_final4 = m->d_w_final4;
-    rc = upload(pack4(4, false), &m->d_w_final4_pad);
+    // run-time-parameterised kernels: always four groups, so fold whenever possible
+    m->dp.folded = can_fold ? 1 : 0;
+    int rc = upload(pack4(4, can_fold, false), &m->d_w_final4_pad);
     if (rc) return rc;
     m->dp.w_final4_pad = m->d_w_final4_pad;
+    // specialised kernels: live channels only; folded only where that does not
+    // cost a channel group (same rule as rhs_mfma.h: spec_folded)
+    const int groups_folded = (dp.D * dp.G + 3) / 4, groups_plain = (dp.C_out + 3) / 4;
+    m->spec_folded = can_fold && groups_folded <= groups_plain;
+    m->dp.fin4_groups = m->spec_folded ? groups_folded : groups_plain;
+    rc = upload(pack4(m->dp.fin4_groups, m->spec_folded, true), &m->d_w_final4);
+    if (rc) return rc;
+    m->dp.w_final4 = m->d_w_final4;
   }
   return DDD_OK;
 }
@@ -480,11 +481,15 @@ int spec_equation(const ddd_model* m, int rows) {
   if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
   if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
   if ((dp.conservative != 0) != ddd::mfma::spec_flux_form(dp.equation)) return -1;
-  if ((dp.folded != 0) != (dp.D <= 2)) return -1;
-  // the three-derivative kernels hard-wire the null-space split 5 + 4 + 2
-  if (dp.D == 3 && !(dp.in_size[0] == 5 && dp.in_size[1] == 4 && dp.in_size[2] == 2 &&
-                     dp.in_start[0] == 0 && dp.in_start[1] == 5 && dp.in_start[2] == 9))
-    return -1;
+  // the kernels hard-wire the null-space split (rhs_mfma.h: spec_in_size) and
+  // whether their packed output layer is folded
+  int start = 0;
+  for (int d = 0; d < dp.D; ++d) {
+    if (dp.in_size[d] != ddd::mfma::spec_in_size(dp.equation, d) || dp.in_start[d] != start)
+      return -1;
+    start += dp.in_size[d];
+  }
+  if (m->spec_folded != ddd::mfma::spec_folded(dp.equation)) return -1;
   return dp.equation;
 }
 

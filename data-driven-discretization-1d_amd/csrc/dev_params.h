@@ -47,9 +47,11 @@ struct DevParams {
   // dsel packed: 2 bits per channel (derivative index) + validity mask, so the
   // hot loop tests one scalar register instead of indexing a 16-SGPR tuple.
   unsigned dsel_bits, dsel_valid;
-  // folded = 1: the output layer's packed weights already contain the
-  // null-space projection (W3 @ nullspace), so output channel 8 d + g IS the
-  // coefficient delta of derivative d, stencil column g (D <= 2 only).
+  // folded = 1: w_final4_pad already contains the null-space projection
+  // (W3 @ nullspace), so its output channel 8 d + g IS the coefficient delta of
+  // derivative d, stencil column g (D <= 2 only; run-time-parameterised kernels.
+  // The specialised kernels know at compile time whether w_final4 is folded:
+  // rhs_mfma.h spec_folded).
   int folded;
   const float* w_input;    // MFMA-packed input layer, 3 x 64
   const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64

@@ -94,11 +94,38 @@ __host__ __device__ constexpr int spec_stencil(int eq) { return spec_flux_form(e
 __host__ __device__ constexpr bool spec_forced_family(int eq) {
   return eq == EQ_BURGERS || eq == EQ_BURGERS_CONS;
 }
+// Null-space sizes of the accuracy layers at the defaults the specialised
+// kernels assume (polynomial_accuracy_order 1, coefficient_grid_min_size 6;
+// checked by capi.hip: spec_equation): centred 7-point stencils: derivative
+// order 1 -> 5, 2 -> 4, 3 -> 3, 4 -> 2; staggered 6-point: 0 -> 5, 1 -> 4,
+// 2 -> 3, 3 -> 2.  Burgers (u_x, u_xx) 5 + 4, KdV (u_x, u_xxx) 5 + 3, KS 5 + 4 + 2,
+// same for the flux forms.
+__host__ __device__ constexpr int spec_in_size(int eq, int d) {
+  return d == 0 ? 5
+         : d == 1 ? ((eq == EQ_KDV || eq == EQ_KDV_CONS) ? 3 : 4)
+         : d == 2 ? 2 : 0;
+}
+__host__ __device__ constexpr int spec_net_channels(int eq) {
+  return spec_in_size(eq, 0) + spec_in_size(eq, 1) + (spec_derivs(eq) > 2 ? spec_in_size(eq, 2) : 0);
+}
+// derivative fed by output channel c of the (unfolded) conv tower
+__host__ __device__ constexpr int spec_channel_deriv(int eq, int c) {
+  return c < spec_in_size(eq, 0) ? 0 : c < spec_in_size(eq, 0) + spec_in_size(eq, 1) ? 1 : 2;
+}
+// Fold the projection (coeff = bias + net @ nullspace) into the output layer
+// when that does not cost a channel group of four: the folded layer emits D x G
+// coefficient channels, the plain one the null-space coordinates and leaves
+// ~7 FMAs per channel to the epilogue.  Flux-form Burgers: 12 vs 9 channels = 3
+// groups either way -> folded.  KdV: 12-14 vs 8 -> 2 groups unfolded.  Non-flux
+// Burgers: 14 vs 9 -> 3 groups unfolded.  KS (D = 3): never folded.
+__host__ __device__ constexpr bool spec_folded(int eq) {
+  return spec_derivs(eq) <= 2 &&
+         (spec_derivs(eq) * spec_stencil(eq) + 3) / 4 <= (spec_net_channels(eq) + 3) / 4;
+}
 // Output channels of the specialised kernels' last layer, in groups of four
-// (final_layer4): D <= 2: the folded layer emits the D x G stencil coefficients
-// (12 or 14 channels); D = 3 (KS): the 5 + 4 + 2 null-space coordinates.
+// (final_layer4).
 __host__ __device__ constexpr int spec_fin_channels(int eq) {
-  return spec_derivs(eq) <= 2 ? spec_derivs(eq) * spec_stencil(eq) : 11;
+  return spec_folded(eq) ? spec_derivs(eq) * spec_stencil(eq) : spec_net_channels(eq);
 }
 __host__ __device__ constexpr int spec_fin_groups(int eq) { return (spec_fin_channels(eq) + 3) / 4; }
 __host__ __device__ constexpr int fin4_regs(int groups) { return (kFin4K * groups + 15) / 16; }
@@ -546,7 +573,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const int nG = kSpec ? spec_stencil(kEq) : p.G;
   const bool flux_form = kSpec ? spec_flux_form(kEq) : (p.conservative != 0);
   const bool fixed = kSpec ? false : (p.fixed != 0);
-  const bool folded = kSpec ? (spec_derivs(kEq) <= 2) : (p.folded != 0);
+  const bool folded = kSpec ? spec_folded(kSpec ? kEq : 0) : (p.folded != 0);
   const int act = kSpec ? (int)ACT_RELU : p.act;
   // specialised kernels: forcing only in the Burgers family, and only in its
   // harmonic-sum form (capi.hip routes anything else to the run-time kernels)
@@ -723,11 +750,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      // specialised three-derivative (KS) kernels: null-space sizes 5 + 4 + 2 at
-      // polynomial accuracy order 1 (checked by capi.hip: spec_equation), so the
-      // channel -> derivative map is a compile-time constant
-      if (kSpec ? c >= 11 : !((p.dsel_valid >> c) & 1u)) continue;
-      const unsigned d = kSpec ? (c < 5 ? 0u : c < 9 ? 1u : 2u) : (p.dsel_bits >> (2 * c)) & 3u;
+      // specialised kernels: the null-space split is known (spec_in_size, checked
+      // by capi.hip: spec_equation), so the channel -> derivative map is a
+      // compile-time constant
+      if (kSpec ? c >= spec_net_channels(kSpec ? kEq : 0) : !((p.dsel_valid >> c) & 1u)) continue;
+      const unsigned d = kSpec ? (unsigned)spec_channel_deriv(kSpec ? kEq : 0, c)
+                               : (p.dsel_bits >> (2 * c)) & 3u;
       const float nv = net[c];
       const float4 n0 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax);
       const float4 n1 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax + 4);
