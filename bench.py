@@ -26,7 +26,9 @@ Timing protocol (every rank):
   2. --warmup W untimed steps (one launch);
   3. barrier + synchronize; the timed region is R back-to-back jobs of exactly
      --steps K steps each (every job: one persistent launch from the same y0 +,
-     for N > 1, the RCCL all-gather of the final states); R = 1 when one job
+     for N > 1, the RCCL all-gather of the final states, which runs on RCCL's
+     stream and overlaps the next job's kernel; every gather is complete before
+     the closing barrier); R = 1 when one job
      lasts >= --min-timed-ms (default 40 ms), otherwise the smallest R that
      fills it.  R is reported as "reps"; "ms_per_step" and "value" are means
      over the R*K timed steps, "roofline.kernel_ms_per_launch" the HIP-event
@@ -88,6 +90,11 @@ def parse_args(argv=None):
                   help='run the timed kernel this long before --warmup (0 disables)')
   ap.add_argument('--min-timed-ms', type=float, default=40.0,
                   help='repeat the K-step job until the timed region lasts this long')
+  ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                  help='collective backend for --gpus > 1: nccl = RCCL over xGMI (the '
+                       'measured configuration); gloo stages the gather through host '
+                       'memory and lets several ranks share one GPU (tests of the N > 1 '
+                       'code path on a one-GPU box; never a headline number)')
   ap.add_argument('--debug-option', action='append', default=[], metavar='NAME=VALUE',
                   help='library A/B switch (ddd_debug_set_option), e.g. no_spec=1; '
                        'logged to stderr, never set in a headline run')
@@ -283,19 +290,38 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   dt = model.equation.time_step
   dtype = torch.float64 if args.state_dtype == 'float64' else torch.float32
   y0 = torch.from_numpy(y0_host).cuda().to(dtype)
-  final = torch.empty((1, batch, n), dtype=dtype, device='cuda')
-  gathered = (torch.empty((world, batch, n), dtype=dtype, device='cuda')
-              if world > 1 else None)
+  # two result / gather buffers: with N > 1 the RCCL gather of job r (its own
+  # stream) overlaps the kernel of job r + 1 -- independent jobs stream through
+  finals = [torch.empty((1, batch, n), dtype=dtype, device='cuda') for _ in range(2)]
+  final = finals[0]
+  host = args.backend == 'gloo'       # gloo: collectives on host copies
+  gathers = ([torch.empty((world * batch, n), dtype=dtype,   # rank slabs concatenated
+                          device='cpu' if host else 'cuda') for _ in range(2)]
+             if world > 1 else None)
+  pending = [None, None]
 
-  def job(num_steps):
+  def gather_final(slot):
+    source = finals[slot][0].cpu() if host else finals[slot][0]
+    pending[slot] = dist.all_gather_into_tensor(gathers[slot], source, async_op=True)
+
+  def wait_slot(slot):
+    if pending[slot] is not None:
+      pending[slot].wait()          # the compute stream waits for that gather
+      pending[slot] = None
+
+  def job(num_steps, slot=0):
+    wait_slot(slot)                 # its buffers are free again
     model.integrate_fixed(y0, num_steps, dt=dt, t0=0.0, scheme=args.scheme,
                           save_every=num_steps, launch_mode=args.launch_mode,
-                          state_dtype=args.state_dtype, out=final)
+                          state_dtype=args.state_dtype, out=finals[slot])
     if world > 1:
-      dist.all_gather_into_tensor(gathered, final[0])
+      gather_final(slot)
 
   def barrier():
+    wait_slot(0)
+    wait_slot(1)
     if world > 1:
+      torch.cuda.synchronize()
       dist.barrier()
     torch.cuda.synchronize()
 
@@ -325,7 +351,7 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   reps = max(1, int(math.ceil(args.min_timed_ms / max(step_ms * args.steps, 1e-6))))
   reps = min(reps, 100000)
   if world > 1:
-    r = torch.tensor([reps], dtype=torch.int64, device='cuda')
+    r = torch.tensor([reps], dtype=torch.int64, device='cpu' if host else 'cuda')
     dist.broadcast(r, 0)
     reps = int(r[0])
 
@@ -339,14 +365,16 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   # no inter-launch gap), on the stream the kernel is launched on
   evts = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(reps)]
-  for e0, e1 in evts:
+  for rep, (e0, e1) in enumerate(evts):
+    slot = rep & 1
+    wait_slot(slot)
     e0.record()
     model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
                           save_every=args.steps, launch_mode=args.launch_mode,
-                          state_dtype=args.state_dtype, out=final)
+                          state_dtype=args.state_dtype, out=finals[slot])
     e1.record()
     if world > 1:
-      dist.all_gather_into_tensor(gathered, final[0])
+      gather_final(slot)
   barrier()
   wall1 = time.perf_counter()
   wall = wall1 - wall0
@@ -354,10 +382,10 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   clocks = sampler.stop(wall0, wall1) if sampler is not None else None
 
   if world > 1:
-    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device='cuda')
+    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device='cpu' if host else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall, kernel_ms = float(t[0]), float(t[1])
-  finite = bool(torch.isfinite(final).all())
+  finite = bool(torch.isfinite(finals[0]).all())
   return dict(wall=wall, kernel_ms=kernel_ms, reps=reps, finite=finite,
               preheat_ms=heated, preheat_launches=heat_launches, clocks=clocks)
 
@@ -430,9 +458,13 @@ def main():
 
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  torch.cuda.set_device(local_rank)
+  device = local_rank % torch.cuda.device_count() if args.backend == 'gloo' else local_rank
+  torch.cuda.set_device(device)
   if world > 1:
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if args.backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+    else:
+      dist.init_process_group('gloo')
 
   import ddd1d_amd
   lib = ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
@@ -492,6 +524,7 @@ def main():
             'state_dtype': args.state_dtype,
             'fma_per_point_eval': model.fma_per_point,
             'parallelism': 'ensemble-shard x{}'.format(world),
+            'backend': args.backend if world > 1 else None,
             'finite': m['finite'],
             'debug_options': args.debug_option,
             'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,

@@ -80,6 +80,26 @@ def test_two_ranks_hip_kernel_and_gather(tmp_path, backend):
   np.testing.assert_array_equal(gathered, want)
 
 
+def test_bench_two_ranks_on_this_box():
+  """bench.py's N > 1 code path (self-launch under torch.distributed.run, agreed
+  repetition count, gather inside the timed region, max over ranks) on whatever
+  this box has: two ranks sharing cuda:0 with the gloo backend.  Not a
+  performance number -- the ranks compete for one GPU."""
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                        '--backend', 'gloo', '--steps', '20', '--warmup', '5', '--batch', '512',
+                        '--preheat-ms', '20', '--min-timed-ms', '5', '--cpu-seconds', '0'],
+                       env=env, capture_output=True, text=True, timeout=900)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+  result = json.loads(line)
+  assert result['n_gpus'] == 2 and result['config']['global_batch'] == 1024
+  assert result['config']['backend'] == 'gloo' and result['config']['finite']
+  assert result['steps'] == 20 and result['reps'] >= 1 and result['value'] > 0
+  assert result['cpu_baseline'] is None and result['secondary'] is None
+
+
 def test_bench_self_launches_its_ranks():
   """`python bench.py --gpus 2` without a torchrun environment starts its own
   ranks (bench.py: relaunch_under_torchrun) and prints one JSON line."""
