@@ -23,6 +23,9 @@ for b in 4096 1024; do
     timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_B$b -o pmc -- python bench.py --batch $b --secondary-batch 0 --steps 1000 --warmup 0 --preheat-ms 0 --min-timed-ms 0 --cpu-seconds 0 > $O/pmc_${c}_B$b.log 2>&1
   done
 done
+for b in 4096 1024; do
+  timeout 600 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_clk_B$b -o pmc -- python bench.py --batch $b --secondary-batch 0 --steps 1000 --warmup 1000 --preheat-ms 200 --min-timed-ms 0 --cpu-seconds 0 > $O/pmc_clk_B$b.log 2>&1
+done
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_persub -o pmc -- python bench.py --launch-mode per_substep --secondary-batch 0 --steps 20 --warmup 0 --preheat-ms 0 --min-timed-ms 0 --cpu-seconds 0 > $O/pmc_${c}_persub.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_stream -o pmc -- python bench.py --equation kdv --baseline-stencils --launch-mode per_substep --batch 262144 --secondary-batch 0 --steps 20 --warmup 0 --preheat-ms 0 --min-timed-ms 0 --cpu-seconds 0 > $O/pmc_${c}_stream.log 2>&1

@@ -1,5 +1,5 @@
 """bench.py helpers that do not need a GPU: the measured-traffic lookup and the
-committed PMC table it reads (profiles/r1_hbm_traffic.json)."""
+committed PMC tables it reads (profiles/r*_hbm_traffic.json, newest first)."""
 import importlib.util
 import json
 import os
@@ -16,9 +16,16 @@ def _bench():
 
 def test_measured_traffic_lookup():
   bench = _bench()
-  table = json.load(open(os.path.join(ROOT, 'profiles', 'r1_hbm_traffic.json')))
-  assert table['entries'], 'PMC table is empty'
-  for entry in table['entries']:
+  tables = [json.load(open(os.path.join(ROOT, 'profiles', name)))
+            for name in bench.TRAFFIC_TABLES]
+  newest = tables[0]
+  assert newest['entries'], 'PMC table is empty'
+  # the default run (north_star target: batch 4096) and configs[1] are profiled
+  for batch in (4096, 1024):
+    got, source = bench.measured_traffic('ConservativeBurgersEquation', 64, batch,
+                                         'persistent', False)
+    assert got and source == 'profiles/' + bench.TRAFFIC_TABLES[0]
+  for entry in newest['entries']:
     m = entry['match']
     got, source = bench.measured_traffic(m['equation'], m['num_points'], m['batch_per_gpu'],
                                          m['launch_mode'], m['fixed'])
