@@ -84,8 +84,8 @@ struct IntegrateArgs {
   void* y_out;      // [n_saved][batch][N] StateT
   int batch;
   int prio_split;   // 1: odd hardware wave slots run at raised priority
-  int ablate;       // profiling only (DDD_ABLATE): bit mask of phases to skip
-  int stagger;      // profiling only (DDD_STAGGER): initial s_sleep count for odd waves
+  int ablate;       // profiling only (debug option "ablate"): bit mask of phases to skip
+  int stagger;      // profiling only (debug option "stagger"): initial s_sleep count for odd waves
   unsigned long long* trace;   // profiling only: [blocks][kTraceSlots] s_memtime stamps
 };
 

@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-// kTrace: s_memtime phase stamps (DDD_TRACE_PTR, profiles/tools/trace_phases.py)
+// kTrace: s_memtime phase stamps (debug option "trace_ptr", profiles/tools/trace_phases.py)
 // are compiled into the run-time-parameterised instantiation and into one
 // dedicated specialised instantiation only: their branches cost ~2 % otherwise.
 template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0)>
@@ -1072,13 +1072,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
   // one of them win every arbitration, which de-synchronises the pair so one
   // wave's VALU / LDS phases overlap the other's MFMA phases
   // (MI355X_MICROARCH.md "Two waves per SIMD", item 4).
-  // DDD_ABLATE (profiling) is honoured by the run-time-parameterised
+  // the ablate mask (profiling: ddd_debug_set_option("ablate")) is honoured by the run-time-parameterised
   // instantiation only (DDD_NO_SPEC=1 selects it for the default models)
   int ablate = kEq >= 0 ? 0 : (a.ablate & 0xff);
   if (kEq < 0 && (a.ablate >> 8) != 0 &&
       ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) != 0))
-    ablate = (a.ablate >> 8) & 0xff;   // DDD_ABLATE high byte: mask for odd wave slots
-  if (a.prio_split) {   // A/B experiments (DDD_PRIO_SPLIT / DDD_STAGGER), off by default
+    ablate = (a.ablate >> 8) & 0xff;   // high byte: mask for odd wave slots
+  if (a.prio_split) {   // A/B experiments (debug options "prio_split" / "stagger"), off by default
     const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xfu;   // HW_ID.wave_id
     const bool odd = (a.prio_split & 2) ? ((blockIdx.x >> 10) & 1u) != 0 : (wave_slot & 1u) != 0;
     if (odd) {
