@@ -850,20 +850,25 @@ template <int kRows, int kWR>
 __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR>& sm,
                                               int block, int batch, Resident& res, bool fast);
 
-// Per-launch setup: resident registers and the per-sample tables in LDS.
+// The forcing of this launch can take the harmonic-sum path (else: per-point sinf).
+template <int kRows, int kWR>
+__device__ __forceinline__ bool forcing_is_fast(const DevParams& p) {
+  const int spg = kRows / p.N;
+  return p.forced && spg * p.P <= Shared<kRows, kWR>::kPmMax && p.n_k <= 6 &&
+         spg * kTrigMax <= Shared<kRows, kWR>::kFkMax && p.P < 256;
+}
+
+// Per-launch setup, part 1: resident registers and the tables in LDS.
 template <int kRows, int kWR, bool kHoist>
-__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
-                                             const Lane& ln, int batch, Resident& res) {
+__device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR>& sm,
+                                              const Lane& ln, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
   const int tid = (int)threadIdx.x;
-  const int block = (int)blockIdx.x;
-  const int spg = kRows / p.N;
   for (int i = tid; i < kTabRows * kGMax; i += kThreads) {
     const int rowi = i / kGMax, g = i % kGMax;
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
-  const bool fast = p.forced && spg * p.P <= Shared<kRows, kWR>::kPmMax && p.n_k <= 6 &&
-                    spg * kTrigMax <= Shared<kRows, kWR>::kFkMax && p.P < 256;
+  const bool fast = forcing_is_fast<kRows, kWR>(p);
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
   if (!p.fixed) {
@@ -917,7 +922,15 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
     *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = tr[0];
     *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = tr[1];
   }
-  setup_samples<kRows, kWR>(p, sm, block, batch, res, fast);
+  return fast;
+}
+
+// Per-launch setup of the persistent integrators and the one-group substep kernel.
+template <int kRows, int kWR, bool kHoist>
+__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
+                                             const Lane& ln, int batch, Resident& res) {
+  const bool fast = setup_weights<kRows, kWR, kHoist>(p, sm, ln, res);
+  setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast);
   return fast;
 }
 
@@ -1015,8 +1028,14 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
   __shared__ Shared<kRows, kWR> sm;
   Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kWR, true>(p, sm, ln, a.batch, res);
+  // the first group's state and forcing rows are requested BEFORE the 115 weight
+  // registers: its input layer and forcing sums run while the hidden layer's
+  // weights are still arriving (loads return in order)
   float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;
+  const bool fast_frc = forcing_is_fast<kRows, kWR>(p);
+  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, blockIdx.x, a.batch, fast_frc);
+  setup_weights<kRows, kWR, true>(p, sm, ln, res);
+  apply_samples<kRows, kWR>(sm, res, s_first);
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     // the next group's state and forcing rows: in flight during this evaluation
     const int nxt = grp + (int)gridDim.x;

@@ -37,8 +37,19 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
   const long rest = total - base;
   const int live = rest < (long)pts ? (int)rest : pts;      // whole samples
   const int i0 = threadIdx.x * kPer;
-  if (i0 < live)
-    *reinterpret_cast<float4*>(tile + i0) = *reinterpret_cast<const float4*>(a.y_in + base + i0);
+  // every global load of the thread is issued up front (the update's other
+  // operands are not needed before the stencil is done: their latency hides
+  // behind the LDS exchange and the arithmetic)
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 base_in = zero4, acc_in4 = zero4;
+  if (i0 < live) {
+    const long gi0 = base + i0;
+    *reinterpret_cast<float4*>(tile + i0) = *reinterpret_cast<const float4*>(a.y_in + gi0);
+    if (a.y_out != nullptr && a.y_base != nullptr && a.y_base != a.y_in)
+      base_in = *reinterpret_cast<const float4*>(a.y_base + gi0);
+    if (a.acc_out != nullptr && a.acc_in != nullptr && a.acc_in != a.y_in)
+      acc_in4 = *reinterpret_cast<const float4*>(a.acc_in + gi0);
+  }
   __syncthreads();
   if (i0 >= live) return;
 
@@ -87,9 +98,7 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
     float4 o = make_float4(a.c1 * r[0], a.c1 * r[1], a.c1 * r[2], a.c1 * r[3]);
     if (a.y_base != nullptr) {
       // stage 0 reads y as both input and base: reuse the staged tile
-      const float4 b = a.y_base == a.y_in
-                           ? own
-                           : *reinterpret_cast<const float4*>(a.y_base + gi);
+      const float4 b = a.y_base == a.y_in ? own : base_in;
       o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
     }
     *reinterpret_cast<float4*>(a.y_out + gi) = o;
@@ -97,9 +106,7 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
   if (a.acc_out != nullptr) {
     float4 o = make_float4(a.c2 * r[0], a.c2 * r[1], a.c2 * r[2], a.c2 * r[3]);
     if (a.acc_in != nullptr) {
-      const float4 b = a.acc_in == a.y_in
-                           ? own
-                           : *reinterpret_cast<const float4*>(a.acc_in + gi);
+      const float4 b = a.acc_in == a.y_in ? own : acc_in4;
       o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
     }
     *reinterpret_cast<float4*>(a.acc_out + gi) = o;

@@ -67,6 +67,37 @@ def test_launch_modes_agree():
     np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('equation,num_points,batch', [
+    ('burgers', 64, 5003),    # one-wave groups: the grid is capped at two per SIMD, so
+    ('burgers', 32, 5003),    # every wavefront walks over 2-3 groups (ragged tail)
+    ('kdv', 64, 4100),
+    ('burgers', 128, 1501),   # 256-row groups, two samples each, last group half empty
+])
+def test_launch_modes_agree_when_groups_outnumber_the_grid(equation, num_points, batch):
+  """The per-substep kernel of the specialised models keeps a machine-sized
+  grid and walks over the row groups (substep_multi_kernel: resident weights,
+  next group's state / forcing prefetched): still bit-equal to the persistent
+  launch, and the sub-sample that sits in second / third passes matches the
+  oracle."""
+  model = make_model(equation, True, num_points=num_points, resample_factor=2)
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  if forcing is not None:
+    model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, batch)
+  dt = model.equation.time_step
+  a = model.integrate_fixed(y0, 6, dt=dt, scheme='midpoint', save_every=3,
+                            launch_mode='persistent').cpu().numpy()
+  b = model.integrate_fixed(y0, 6, dt=dt, scheme='midpoint', save_every=3,
+                            launch_mode='per_substep').cpu().numpy()
+  np.testing.assert_array_equal(a, b)
+  assert np.isfinite(b).all()
+  rows = np.array([0, batch // 2, batch - 2, batch - 1])     # first and later passes
+  sub_forcing = None if forcing is None else {k: v[rows] for k, v in forcing.items()}
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 6, 3,
+                                y0[rows], forcing=sub_forcing)
+  assert rel_err(b[:, rows], want) < TOL
+
+
 def test_rk_substep_composes_midpoint():
   """ddd_rk_substep x2 == one midpoint step of ddd_integrate_fixed."""
   import torch
