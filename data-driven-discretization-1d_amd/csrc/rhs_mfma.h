@@ -498,6 +498,7 @@ struct Resident {
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
+  float frc_mask[8];        // 1 where entry i of this lane's first 8-mode trip belongs to its run
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
   int frc_run;              // its run of modes: (float offset into Shared::pm) | count << 16
                             // | (index of the sum in Shared::fk) << 24; 0: lane carries none
@@ -524,7 +525,12 @@ __device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows,
   }
 }
 
-template <int kRows, int kWR>
+// kMasked (kernels that keep Resident::frc_mask): the first trip multiplies by the
+// lane's 0 / 1 masks instead of compare + select per entry.  fma(v, 1, acc) is
+// acc + v and fma(v, 0, acc) is acc for every finite v (the staged values are
+// a sin / a cos of finite angles, the padding is zeroed at setup), so both
+// forms give the same bits.
+template <int kRows, int kWR, bool kMasked = false>
 __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Resident& res) {
   const int cnt = (res.frc_run >> 16) & 0xff;
   const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm) + (res.frc_run & 0xffff);
@@ -532,7 +538,16 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Re
   // eight independent LDS reads per trip (runs average P / n_k = 7 modes);
   // entries past the run add an exact 0, so the sum keeps mode order
   // (reads past the run stay inside Shared::pm: it carries 8 entries of padding)
-  for (int m = 0; m < cnt; m += 8) {
+  int first = 0;
+  if (kMasked) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = pm[2 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = fmaf(v[i], res.frc_mask[i], acc);
+    first = 8;
+  }
+  for (int m = first; m < cnt; m += 8) {
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = pm[2 * (m + i)];
@@ -674,7 +689,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       // the hidden layer's last activations are on their way to LDS: fill the
       // wait with the forcing sums the next evaluation needs
       if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
-      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR>(sm, res);
+      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kKeepRows>(sm, res);
       __syncthreads();
       f32x4 acc4[kNG];
       if (!(ablate & 4)) {
@@ -869,6 +884,9 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
   const bool fast = forcing_is_fast<kRows, kWR>(p);
+  // staged (sample, mode) values: zero once, so that reads past a run are finite
+  for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
+    sm.pm[i] = make_float2(0.0f, 0.0f);
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
   if (!p.fixed) {
@@ -978,6 +996,9 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& 
   constexpr int kThreads = kRows / kWR * 64;
   res.frc_a = s.a; res.frc_omega = s.omega; res.frc_phi = s.phi;
   res.frc_run = s.run;
+  const int cnt = (s.run >> 16) & 0xff;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) res.frc_mask[i] = i < cnt ? 1.0f : 0.0f;
   res.fk_next = 0.0f;
   for (int i = (int)threadIdx.x; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
 }
