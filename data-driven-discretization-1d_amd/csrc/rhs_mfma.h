@@ -689,7 +689,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       // the hidden layer's last activations are on their way to LDS: fill the
       // wait with the forcing sums the next evaluation needs
       if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
-      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kKeepRows>(sm, res);
+      // (masked sums where registers allow: the folded kernels; the unfolded
+      // non-flux Burgers kernel needs them for the projection)
+      constexpr bool kMaskedSums = kKeepRows && spec_folded(kSpec ? kEq : 0);
+      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
       __syncthreads();
       f32x4 acc4[kNG];
       if (!(ablate & 4)) {
