@@ -301,11 +301,17 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
   float b0[kT], b1[kT], b2[kT];
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
-    if (kAddr) {
+    if (kAddr && kShfl) {
       const int uni = __float_as_int(un);
       b0[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][0], uni));
       b1[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][1], uni));
       b2[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(bperm[t][2], uni));
+    } else if (kAddr) {
+      // four-wave groups: the same resident byte addresses, into Shared::un
+      const char* __restrict__ ub = reinterpret_cast<const char*>(us);
+      b0[t] = *reinterpret_cast<const float*>(ub + bperm[t][0]);
+      b1[t] = *reinterpret_cast<const float*>(ub + bperm[t][1]);
+      b2[t] = *reinterpret_cast<const float*>(ub + bperm[t][2]);
     } else {
       const int r0 = half ? rows[t][1] : rows[t][0];              // taps 0 / 1
       const int r1 = half ? rows[t][3] : rows[t][2];              // taps 2 / 3
@@ -316,7 +322,7 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
     }
     b2[t] = half ? 1.0f : b2[t];
   }
-  if (kAddr) __builtin_amdgcn_sched_group_barrier(0x080, 3 * kT, 0);   // the permutes first
+  if (kAddr && kShfl) __builtin_amdgcn_sched_group_barrier(0x080, 3 * kT, 0);   // the permutes first
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
 #pragma unroll
@@ -603,7 +609,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // the run-time-parameterised kernels all four (w_final4_pad)
   constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 4;
   // specialised one-wave integrators keep loop invariants in registers
-  constexpr bool kKeepRows = kOneWave && kWR == 64 && kHoist && kEq >= 0;
+  constexpr bool kKeepRows = kWR == 64 && kHoist && kEq >= 0;
   const int tid = opaque((int)threadIdx.x);
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
   if (ln.owner) sm.u[ln.row] = u;
@@ -643,8 +649,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   if (!kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < nG) ? sm.u[pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
-                                    : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
+      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g]
+                               : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                      : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
 
   float net[16];
@@ -898,39 +905,42 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
     // loop invariants the specialised one-wave integrators keep resident
     // (kHoist: the persistent kernels; a single fused substep has no loop)
-    if (kHoist && kRows == 64 && kWR == 64) {
+    if (kHoist && kWR == 64) {
 #pragma unroll
       for (int s = 0; s < fin4_regs(4); ++s)   // buffer holds fin4_regs(4) rows (zero padded)
         res.w_fin4[s] = p.w_final4[s * 64 + ln.lane];
       {
         int rows[kKW];
-        tap_rows<true>(ln, ln.row, p.N, rows);
+        tap_rows<kRows == 64>(ln, ln.row, p.N, rows);
 #pragma unroll
         for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
           res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
         const int half = ln.lane >> 5;
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
-          tap_rows<true>(ln, t2 * 32 + (ln.lane & 31), p.N, rows);
+          tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, rows);
 #pragma unroll
           for (int k = 0; k < kKW; ++k)
             res.hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
                                         64 * half);
-          // input layer: taps 0 / 1, taps 2 / 3, tap 4 (rows < 64 = lanes of this wavefront)
+          // input layer: taps 0 / 1, taps 2 / 3, tap 4, as byte addresses (one-wave
+          // groups: ds_bpermute lane addresses, rows < 64; else into Shared::un)
           res.in_perm[t2][0] = opaque(4 * (half ? rows[1] : rows[0]));
           res.in_perm[t2][1] = opaque(4 * (half ? rows[3] : rows[2]));
           res.in_perm[t2][2] = opaque(4 * rows[4]);
         }
       }
       const int gl = p.G >> 1;
+      const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;
 #pragma unroll
       for (int g = 0; g < kGMax; ++g)
-        res.pch_idx[g] = opaque(((ln.pos + g - gl) & (p.N - 1)) | ln.base);
+        res.pch_idx[g] = opaque(pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                     : wrap_row(ln.base, ln.pos, g - gl, p.N));
     }
   }
 #pragma unroll
   for (int i = 0; i < kTrigMax / 4; ++i) res.trig[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (fast && kHoist && kRows == 64 && kWR == 64) {
+  if (fast && kHoist && kWR == 64) {
     const float4* __restrict__ tr =
         reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
 #pragma unroll
