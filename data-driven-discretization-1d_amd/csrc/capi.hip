@@ -214,6 +214,7 @@ void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
   dp->G = cfg.stencil_size;
   dp->eta = (float)cfg.eta;
   dp->stddev = (float)cfg.standard_deviation;
+  dp->inv_stddev = (float)(1.0 / (double)dp->stddev);
   dp->inv_dx = (float)(1.0 / cfg.dx);
   dp->conservative = is_conservative(cfg.equation) ? 1 : 0;
 }
@@ -780,6 +781,7 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
                 "weno_reconstruction needs a Godunov-flux equation (u_minus, u_plus)");
   }
   m->dp.stddev = 1.0f;
+  m->dp.inv_stddev = 1.0f;
   m->fma_per_point = (int64_t)cfg->num_derivatives * cfg->stencil_size;
   std::vector<float> sv(stencils, stencils + n_stencils);
   rc = upload(sv, &m->d_bias);

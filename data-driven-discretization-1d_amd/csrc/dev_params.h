@@ -27,6 +27,7 @@ struct DevParams {
   // equation + grid
   int equation, N, D, G;
   float eta, stddev, inv_dx;
+  float inv_stddev;    // RN(1 / stddev): seed of the three-instruction division in rhs_mfma.h
   int conservative;    // flux form: needs the staggered difference
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net

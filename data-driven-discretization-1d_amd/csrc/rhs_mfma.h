@@ -628,7 +628,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
         tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
     }
   }
-  const float un_reg = u / p.stddev;   // model.py:450-451, a true division
+  // model.py:450-451: net = u / std.  Three FMAs-class instructions instead of
+  // the 12 of the IEEE division sequence: q = RN(u r), r = RN(1 / std), then one
+  // Newton step on the residual, q' = fma(fma(-q, std, u), r, q) -- the
+  // correctly rounded quotient except for rare last-bit cases (|error| <= 1 ulp),
+  // NaN / Inf propagate; every VALU instruction here is matrix-pipe time.
+  const float q_un = u * p.inv_stddev;
+  const float un_reg = fmaf(fmaf(-q_un, p.stddev, u), p.inv_stddev, q_un);
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
   if (!fixed && !kOneWave && ln.owner) sm.un[ln.row] = un_reg;
   // harmonic forcing sums of THIS evaluation's time: computed during the
