@@ -631,8 +631,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // model.py:450-451: net = u / std.  Three FMAs-class instructions instead of
   // the 12 of the IEEE division sequence: q = RN(u r), r = RN(1 / std), then one
   // Newton step on the residual, q' = fma(fma(-q, std, u), r, q) -- the
-  // correctly rounded quotient except for rare last-bit cases (|error| <= 1 ulp),
-  // NaN / Inf propagate; every VALU instruction here is matrix-pipe time.
+  // correctly rounded quotient (bit-equal to the division on 2M random inputs per
+  // standard deviation, tests/test_cpu_mfma_emulation.py); NaN propagates, an
+  // overflowing quotient (a diverged state) becomes NaN instead of Inf; every
+  // VALU instruction here is matrix-pipe time.
   const float q_un = u * p.inv_stddev;
   const float un_reg = fmaf(fmaf(-q_un, p.stddev, u), p.inv_stddev, q_un);
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)

@@ -219,3 +219,34 @@ def test_emulated_final4_matches_direct_conv(n, n_ch):
   want += b
   np.testing.assert_allclose(got[..., :n_ch], want, rtol=1e-12, atol=1e-12)
   assert np.all(got[..., n_ch:] == 0)
+
+
+def test_three_instruction_division_equals_ieee_division():
+  """rhs_mfma.h scales the input with q = RN(u r), q' = fma(fma(-q, std, u), r, q),
+  r = RN(1 / std), instead of the 12-instruction IEEE division sequence
+  (model.py:450-451: net = u / std).  Emulated here with exact float64 products
+  (a float32 x float32 product is exact in float64, so each fma is one rounding):
+  the corrected quotient equals float32 division bit for bit on random inputs,
+  the plain reciprocal multiply does not."""
+  rs = np.random.RandomState(0)
+  for std in (0.7917, 0.594, 0.299, 1.0, 0.123456):   # Burgers / KdV / KS standard deviations
+    s = np.float32(std)
+    r = np.float32(1.0 / np.float64(s))
+    u = np.concatenate([(rs.randn(400000) * 2).astype(np.float32),
+                        np.float32([0.0, -0.0, 1e-30, -1e30, 1e37])])
+    q = (u * r).astype(np.float32)
+    e = (np.float64(u) - np.float64(q) * np.float64(s)).astype(np.float32)
+    q2 = (np.float64(q) + np.float64(e) * np.float64(r)).astype(np.float32)
+    want = (u / s).astype(np.float32)
+    np.testing.assert_array_equal(q2, want)
+    # a quotient that overflows (|u| > FLT_MAX std: a diverged state) comes out
+    # non-finite either way -- Inf from the division, NaN from the correction
+    # step (Inf - Inf); divergence is reported as non-finite rows, not clamped
+    with np.errstate(all='ignore'):
+      big = np.float32(3.4e38)
+      qb = np.float32(big * r)
+      eb = np.float32(np.float64(big) - np.float64(qb) * np.float64(s))
+      assert not np.isfinite(np.float32(np.float64(qb) + np.float64(eb) * np.float64(r))) \
+          or np.isfinite(big / s)
+    if std != 1.0:
+      assert np.mean(q != want) > 0.05     # the uncorrected product is NOT the quotient
