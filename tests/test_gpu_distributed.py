@@ -100,6 +100,39 @@ def test_bench_two_ranks_on_this_box():
   assert result['cpu_baseline'] is None and result['secondary'] is None
 
 
+def test_bench_rccl_path_with_one_rank():
+  """The RCCL calls bench.py makes with N > 1 -- init with device_id, broadcast of
+  the repetition count, async all_gather_into_tensor of a [batch, x] slab into
+  a [world * batch, x] buffer, wait, all_reduce(MAX), barrier -- on DEVICE
+  tensors with backend "nccl" in a world of ONE rank, which one GPU can host.
+  Catches API / shape mistakes before the first multi-GPU run."""
+  code = r"""
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='%d', RANK='0', WORLD_SIZE='1',
+                  LOCAL_RANK='0')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+r = torch.tensor([7], dtype=torch.int64, device='cuda'); dist.broadcast(r, 0)
+final = torch.arange(512 * 64, dtype=torch.float32, device='cuda').reshape(1, 512, 64)
+gathered = torch.empty((1 * 512, 64), dtype=torch.float32, device='cuda')
+work = dist.all_gather_into_tensor(gathered, final[0], async_op=True)
+work.wait()
+t = torch.tensor([1.5, 2.5], dtype=torch.float64, device='cuda')
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+assert int(r[0]) == 7 and torch.equal(gathered, final[0]) and float(t[1]) == 2.5
+dist.destroy_process_group()
+print('RCCL_ONE_RANK_OK')
+"""
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  out = subprocess.run([sys.executable, '-c', code % port], env=env, capture_output=True,
+                       text=True, timeout=600)
+  assert out.returncode == 0 and 'RCCL_ONE_RANK_OK' in out.stdout, out.stderr[-3000:]
+
+
 def test_bench_self_launches_its_ranks():
   """`python bench.py --gpus 2` without a torchrun environment starts its own
   ranks (bench.py: relaunch_under_torchrun) and prints one JSON line."""
