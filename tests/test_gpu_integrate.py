@@ -98,6 +98,37 @@ def test_launch_modes_agree_when_groups_outnumber_the_grid(equation, num_points,
   assert rel_err(b[:, rows], want) < TOL
 
 
+@pytest.mark.parametrize('equation,num_points,batch', [
+    ('burgers', 48, 11),      # 256-row groups, 5 samples each, 16 spare rows
+    ('burgers', 200, 3),      # one sample per group, 56 spare rows
+    ('kdv', 100, 5),
+    ('ks', 96, 4),
+])
+def test_trajectories_on_grids_that_are_not_powers_of_two(equation, num_points, batch):
+  """The 256-row specialised integrators keep their operand-row offsets, patch
+  indices and input addresses resident; for N that is not a power of two they
+  come from the general wrap (tap_rows / wrap_row), spare rows read themselves.
+  Persistent and per-substep launches agree bit for bit and match the oracle."""
+  model = make_model(equation, True, num_points=num_points, resample_factor=2)
+  assert model.kernel_name == 'mfma_f32_r256'
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  if forcing is not None:
+    model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, batch)
+  dt = model.equation.time_step
+  steps = 20 if equation == 'burgers' else 40
+  a = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps // 2,
+                            launch_mode='persistent').cpu().numpy()
+  b = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps // 2,
+                            launch_mode='per_substep').cpu().numpy()
+  np.testing.assert_array_equal(a, b)
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps,
+                                steps // 2, y0, forcing=forcing)
+  err = rel_err(a, want)
+  print(equation, num_points, 'rel err {:.2e}'.format(err))
+  assert err < TOL
+
+
 def test_rk_substep_composes_midpoint():
   """ddd_rk_substep x2 == one midpoint step of ddd_integrate_fixed."""
   import torch
