@@ -508,6 +508,8 @@ struct Resident {
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
   int frc_run;              // its run of modes: (float offset into Shared::pm) | count << 16
                             // | (index of the sum in Shared::fk) << 24; 0: lane carries none
+  int frc_slot;             // index of this lane's sum in Shared::fk (fixed by the lane, not by
+                            // the sample), -1: the lane carries no (sample, k, sin|cos) slot
 };
 
 // Forcing, phases 1 + 2, for time t:
@@ -645,8 +647,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // epilogue of the previous evaluation; the next barrier orders the readers)
   __syncthreads();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
-  if (forced && fast_forcing && ((res.frc_run >> 16) & 0xff) != 0)   // empty runs stay 0
-    sm.fk[(unsigned)res.frc_run >> 24] = res.fk_next;
+  if (forced && fast_forcing && res.frc_slot >= 0)   // (an empty run publishes its 0)
+    sm.fk[res.frc_slot] = res.fk_next;
 
   // patches[i] = u[(x + i - G/2) mod N]   (model.extract_patches, model.py:516-533)
   // Four-wave groups must read them now (other waves rewrite sm.u as soon as
@@ -902,6 +904,12 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
   const bool fast = forcing_is_fast<kRows, kWR>(p);
+  {
+    const int spg = kRows / p.N;
+    const int sl = row_sample(tid >> 1, 1.0f / (float)max(p.n_k, 1));   // exact
+    res.frc_slot = (fast && tid < spg * p.n_k * 2)
+                       ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
+  }
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
     sm.pm[i] = make_float2(0.0f, 0.0f);
@@ -1011,7 +1019,9 @@ __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int blo
   return s;
 }
 
-template <int kRows, int kWR>
+// kReset: also forget the pending harmonic sum and clear Shared::fk (a fresh
+// launch); without it only the parameters the NEXT sums are computed from change.
+template <int kRows, int kWR, bool kReset = true>
 __device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& res,
                                               const SampleSetup& s) {
   constexpr int kThreads = kRows / kWR * 64;
@@ -1020,8 +1030,10 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& 
   const int cnt = (s.run >> 16) & 0xff;
 #pragma unroll
   for (int i = 0; i < 8; ++i) res.frc_mask[i] = i < cnt ? 1.0f : 0.0f;
-  res.fk_next = 0.0f;
-  for (int i = (int)threadIdx.x; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
+  if (kReset) {
+    res.fk_next = 0.0f;
+    for (int i = (int)threadIdx.x; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
+  }
 }
 
 template <int kRows, int kWR>
@@ -1078,36 +1090,41 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
   const SampleSetup s_first = fetch_samples<kRows, kWR>(p, blockIdx.x, a.batch, fast_frc);
   setup_weights<kRows, kWR, true>(p, sm, ln, res);
   apply_samples<kRows, kWR>(sm, res, s_first);
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     // the next group's state and forcing rows: in flight during this evaluation
     const int nxt = grp + (int)gridDim.x;
+    const bool more = nxt < groups;
     Lane ln_next = ln;
-    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0};
     float u_next = 0.0f;
-    if (nxt < groups) {
+    if (more) {
       ln_next = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, nxt);
       u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
-      s_next = fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc);
+      // from here on the harmonic sums computed are the NEXT group's: this
+      // group's are already in res.fk_next and are published by eval_rhs
+      apply_samples<kRows, kWR, false>(sm, res,
+                                       fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc));
     }
     // the update's other operands: requested now, consumed after the evaluation
     const float base = (ln.active && a.y_out != nullptr && a.y_base != nullptr)
                            ? a.y_base[ln.gidx] : 0.0f;
     const float acc_in = (ln.active && a.acc_out != nullptr && a.acc_in != nullptr)
                              ? a.acc_in[ln.gidx] : 0.0f;
-    if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
+    // `more`: the evaluation also prepares the sums of the next group (same time,
+    // other samples) at its layer boundaries, as the persistent integrator does
+    // for its next stage; the last group skips that (mask 64)
     const float f = eval_rhs<kRows, kWR, true, kEq, false>(p, sm, a.batch, u, (float)a.t,
                                                            (float)a.t, res, fast_frc, nullptr,
-                                                           nullptr, 64, nullptr, grp);
+                                                           nullptr, more ? 0 : 64, nullptr, grp);
     if (ln.active) {
       // (x + c f with x = 0 when there is no base array: the same bits as c f)
       if (a.y_out != nullptr) a.y_out[ln.gidx] = base + a.c1 * f;
       if (a.acc_out != nullptr) a.acc_out[ln.gidx] = acc_in + a.c2 * f;
     }
-    if (nxt < groups) {
+    if (more) {
       __syncthreads();   // this group's epilogue has read sm.fk / sm.u
       ln = ln_next;
       u = u_next;
-      apply_samples<kRows, kWR>(sm, res, s_next);
     }
   }
 }
