@@ -227,8 +227,9 @@ int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias
   std::memset(dp.bias8, 0, sizeof(dp.bias8));
   dp.dsel_bits = 0;
   dp.dsel_valid = 0;
-  for (int d = 0; d < dp.D; ++d)
-    for (int g = 0; g < dp.G; ++g) dp.bias8[d][g] = bias[d * dp.G + g];
+  if (bias != nullptr)
+    for (int d = 0; d < dp.D; ++d)
+      for (int g = 0; g < dp.G; ++g) dp.bias8[d][g] = bias[d * dp.G + g];
   if (nullspace != nullptr) {
     for (int d = 0; d < dp.D; ++d)
       for (int j = 0; j < dp.in_size[d]; ++j) {
@@ -291,8 +292,22 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     // epilogue's projection disappears.  Deviation from the reference's
     // operation order: O(1 ulp) of the deltas, far inside the 1e-5 tolerance.
     std::vector<float> wf, bf;
-    const bool can_fold = dp.D <= 2 && !g_debug.no_fold;
-    if (can_fold) {
+    const bool projected = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao > 0;
+    const bool direct_coeffs = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0;
+    bool can_fold = projected && dp.D <= 2 && !g_debug.no_fold;
+    if (direct_coeffs) {
+      // the net emits the D x G coefficients themselves (model.py:460-475): the
+      // same channel layout as a folded layer (8 d + g), nothing to project
+      can_fold = true;
+      wf.assign((size_t)5 * 32 * 16, 0.0f);
+      bf.assign(16, 0.0f);
+      for (int d = 0; d < dp.D; ++d)
+        for (int g = 0; g < dp.G; ++g) {
+          for (int tc = 0; tc < 5 * 32; ++tc)
+            wf[(size_t)tc * 16 + 8 * d + g] = w_nat[(size_t)tc * dp.C_out + d * dp.G + g];
+          bf[8 * d + g] = b_nat[d * dp.G + g];
+        }
+    } else if (can_fold) {
       wf.assign((size_t)5 * 32 * 16, 0.0f);
       bf.assign(16, 0.0f);
       for (int d = 0; d < dp.D; ++d)
@@ -368,8 +383,11 @@ void decide_mfma(ddd_model* m) {
   if (dp.G > ddd::kGMax) no("stencil wider than 8");
   if (dp.fixed && dp.weno) no("WENO reconstruction");
   if (!dp.fixed) {
-    if (dp.target != ddd::TARGET_COEFFICIENTS) no("model_target is not 'coefficients'");
-    if (dp.pao <= 0) no("polynomial_accuracy_order is 0");
+    // direct heads (space_derivatives / time_derivative / flux: D or 1 output
+    // channels) and polynomial_accuracy_order = 0 (D x G coefficient channels,
+    // no projection) run on the run-time-parameterised MFMA kernels
+    if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2)
+      no("polynomial_accuracy_order 0 with more than two derivatives");
     if (dp.F != ddd::mfma::kF) no("filter_size != 32");
     if (dp.K != ddd::mfma::kKW) no("kernel_size != 5");
     if (dp.L < 2) no("fewer than 2 conv layers");
@@ -478,6 +496,7 @@ int spec_equation(const ddd_model* m, int rows) {
     if (!fast) return -1;
   }
   if (dp.fixed || dp.L != 3 || dp.act != ddd::ACT_RELU) return -1;
+  if (dp.target != ddd::TARGET_COEFFICIENTS || dp.pao <= 0) return -1;
   if (dp.equation < ddd::EQ_BURGERS || dp.equation > ddd::EQ_KS_CONS) return -1;
   if (dp.D != ddd::mfma::spec_derivs(dp.equation)) return -1;
   if (dp.G != ddd::mfma::spec_stencil(dp.equation)) return -1;
@@ -751,7 +770,7 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   if (!rc) {
     decide_mfma(m);
     if (m->mfma_ok) {
-      rc = upload_padded_tables(m, nullspace, bias);
+      rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr);
       if (!rc) rc = pack_mfma_weights(m, weights);
     }
   }

@@ -597,6 +597,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const bool flux_form = kSpec ? spec_flux_form(kEq) : (p.conservative != 0);
   const bool fixed = kSpec ? false : (p.fixed != 0);
   const bool folded = kSpec ? spec_folded(kSpec ? kEq : 0) : (p.folded != 0);
+  // what the tower predicts (model.py:579-640): stencil coefficients (default),
+  // the spatial derivatives, the time derivative or the flux themselves
+  const int target = kSpec ? (int)TARGET_COEFFICIENTS : p.target;
   const int act = kSpec ? (int)ACT_RELU : p.act;
   // specialised kernels: forcing only in the Burgers family, and only in its
   // harmonic-sum form (capi.hip routes anything else to the run-time kernels)
@@ -810,11 +813,29 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       }
     }
   }
+  if (!kSpec && !fixed && p.pao <= 0 && p.unbiased) {
+    // ensure_unbiased_coefficients (model.py:471-475): subtract the mean over
+    // the stencil (same order of operations as the generic kernel)
+#pragma unroll
+    for (int d = 0; d < kMaxDerivs; ++d) {
+      if (d >= nD) continue;
+      float mean = 0.0f;
+#pragma unroll
+      for (int g = 0; g < kGMax; ++g) if (g < nG) mean += cf[d][g];
+      mean = mean / (float)nG;
+#pragma unroll
+      for (int g = 0; g < kGMax; ++g) if (g < nG) cf[d][g] = cf[d][g] - mean;
+    }
+  }
   float dv[kMaxDerivs];
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d) {
     dv[d] = 0.0f;
     if (d < nD) {
+      if (!kSpec && target == TARGET_SPACE_DERIVATIVES) {   // predicted directly
+        dv[d] = net[d];
+        continue;
+      }
 #pragma unroll
       for (int g = 0; g < kGMax; ++g)   // folded: the bias rides in the output layer's bias row
         if (!folded) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
@@ -838,7 +859,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 
   // ---- equation of motion ------------------------------------------------------
   float r = equation_rhs_or_flux(eqn, u, dv, p.eta);
-  if (flux_form) {
+  // direct heads: the tower's single channel IS u_t (no flux difference, whatever
+  // the equation's form) or the flux (model.predict_flux_directly returns
+  // +staggered_first_derivative(flux), model.py:609-615)
+  const bool direct_time = !kSpec && !fixed && target == TARGET_TIME_DERIVATIVE;
+  const bool direct_flux = !kSpec && !fixed && target == TARGET_FLUX;
+  if (direct_time || direct_flux) r = net[0];
+  if ((flux_form && !direct_time) || direct_flux) {
     float fnext;
     if (kOneWave) {
       // whole samples live in this wavefront: the right neighbour's flux comes
@@ -853,7 +880,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       __syncthreads();
       fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     }
-    r = -(p.inv_dx * (fnext - r));   // equations.staggered_first_derivative
+    r = p.inv_dx * (fnext - r);      // equations.staggered_first_derivative
+    if (!direct_flux) r = -r;        // flux forms: u_t = -d(flux)/dx
   }
   if (forced && !(ablate & 1)) {
     if (kSpec || fast_forcing) {

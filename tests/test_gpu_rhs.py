@@ -100,13 +100,49 @@ def test_network_variants_mfma(overrides):
   print(overrides, mfma_err, generic_err)
 
 
+@pytest.mark.parametrize('equation', ['burgers', 'kdv'])
 @pytest.mark.parametrize('overrides', [
-    dict(num_layers=1), dict(filter_size=16), dict(kernel_size=3),
-    dict(kernel_size=4), dict(coefficient_grid_min_size=9),
     dict(polynomial_accuracy_order=0),
     dict(polynomial_accuracy_order=0, ensure_unbiased_coefficients=True),
     dict(model_target='space_derivatives'),
     dict(model_target='time_derivative'), dict(model_target='flux'),
+])
+def test_direct_heads_on_mfma(equation, overrides):
+  """training_test.py:54-83 variants whose conv tower is the default one: the
+  D x G coefficients without the accuracy projection (model.py:460-475, with
+  and without mean subtraction) and the heads that predict the derivatives, u_t
+  or the flux directly (model.py:551-615) run on the MFMA tower too; both kernel
+  families against the oracle, all views."""
+  conservative = not overrides.get('ensure_unbiased_coefficients', False)
+  model = make_model(equation, conservative, num_points=64, **overrides)
+  assert model.kernel_name.startswith('mfma_f32'), overrides
+  y0 = random_phase_ic(model.equation, 5)
+  forcing = batch_forcing(5)
+  model.set_forcing(forcing)
+  tol = 1e-4 if overrides.get('polynomial_accuracy_order', 1) == 0 else TOL
+  mfma_err = _check_all_views(model, y0, 0.2, forcing, tol)
+  model.set_kernel('mfma256')
+  _check_all_views(model, y0, 0.2, forcing, tol)
+  model.set_kernel('generic')
+  generic_err = _check_all_views(model, y0, 0.2, forcing, tol)
+  print(equation, overrides, mfma_err, generic_err)
+  # and over a few steps of the persistent integrator
+  model.set_kernel('auto')
+  dt = model.equation.time_step
+  got = model.integrate_fixed(y0, 10, dt=dt, scheme='midpoint', save_every=10).cpu().numpy()
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 10, 10, y0,
+                                forcing=forcing if equation == 'burgers' else None)
+  assert rel_err(got, want) < tol
+
+
+def test_accuracy_order_zero_with_three_derivatives_stays_generic():
+  model = make_model('ks', True, num_points=64, polynomial_accuracy_order=0)
+  assert model.kernel_name == 'generic'       # 3 x 6 = 18 coefficient channels > 16
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=1), dict(filter_size=16), dict(kernel_size=3),
+    dict(kernel_size=4), dict(coefficient_grid_min_size=9),
     dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
