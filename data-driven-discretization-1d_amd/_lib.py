@@ -93,6 +93,12 @@ SIGNATURES = {
                                                ctypes.c_double, ctypes.c_int,
                                                ctypes.c_int, _V, _V,
                                                ctypes.c_int, _V]),
+    'ddd_integrate_adaptive_f64': (ctypes.c_int, [_V, _D, ctypes.c_int,
+                                                  ctypes.c_double,
+                                                  ctypes.c_double,
+                                                  ctypes.c_double,
+                                                  ctypes.c_longlong, _V, _V,
+                                                  _V, _V, ctypes.c_int, _V]),
     'ddd_time_derivative_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
                                                ctypes.c_int, _V]),
     'ddd_rk_substep_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,

@@ -175,6 +175,9 @@ struct ddd_model {
   double* d_kernels = nullptr;
   double* d_scratch64 = nullptr;
   size_t scratch64_doubles = 0;
+  // output times of ddd_integrate_adaptive_f64
+  double* d_times = nullptr;
+  size_t times_capacity = 0;
   // scratch for the per-substep launch mode
   float* d_scratch = nullptr;
   size_t scratch_floats = 0;
@@ -902,6 +905,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_w_final4); free_dev(m->d_w_final4_pad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
+  free_dev(m->d_times);
   if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
   if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
   delete m;
@@ -1167,6 +1171,72 @@ int ddd_integrate_fixed_f64(ddd_model* m, int scheme, double t0, double dt, int 
   a.t0 = t0; a.dt = dt; a.n_steps = n_steps; a.save_every = save_every;
   a.y0 = y0; a.y_out = y_out; a.batch = batch;
   return launch_integrate<double>(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, double rtol,
+                               double atol, double max_step, long long max_attempts,
+                               const double* y0, double* y_out, int32_t* nfev,
+                               int32_t* status, int batch, void* stream_) {
+  int rc = check_batch(m, batch);
+  if (rc) return rc;
+  if (times == nullptr || n_times < 1)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "times must hold at least one value");
+  for (int i = 0; i < n_times; ++i)
+    if (!std::isfinite(times[i]) || (i > 0 && !(times[i] > times[i - 1])))
+      return fail(DDD_ERR_INVALID_ARGUMENT, "times must be finite and strictly increasing");
+  if (!(rtol > 0.0) || !(atol >= 0.0) || !(max_step > 0.0))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "rtol and max_step must be positive, atol >= 0");
+  if (batch > 0 && (!y0 || !y_out || !nfev || !status))
+    return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (m->kernel != DDD_KERNEL_MFMA)
+    return fail(DDD_ERR_UNSUPPORTED,
+                "the on-device adaptive integrator runs on the MFMA kernel family only (%s)",
+                m->mfma_reason.c_str());
+  if (batch == 0) return DDD_OK;
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (m->times_capacity < (size_t)n_times) {
+    DDD_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read the old table
+    free_dev(m->d_times);
+    m->d_times = nullptr;
+    m->times_capacity = 0;
+    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_times), (size_t)n_times * sizeof(double)));
+    m->times_capacity = (size_t)n_times;
+  }
+  DDD_HIP(hipMemcpyAsync(m->d_times, times, (size_t)n_times * sizeof(double),
+                         hipMemcpyHostToDevice, stream));
+  ddd::AdaptiveArgs a{};
+  a.times = m->d_times; a.n_times = n_times;
+  a.rtol = rtol; a.atol = atol; a.max_step = max_step;
+  a.y0 = y0; a.y_out = y_out; a.nfev = nfev; a.status = status; a.batch = batch;
+  if (max_attempts <= 0) {
+    // generous default: a thousand times the attempts of a run at max_step
+    const double span = times[n_times - 1] - times[0];
+    max_attempts = (long long)std::min(1e15, std::ceil(span / max_step) * 1000.0 + 100000.0);
+  }
+  a.max_attempts = max_attempts;
+  m->last_batch = batch;
+  m->last_launch_streamed = false;
+  m->dp.dpp_rol = dpp_wave_rol_ok();
+  MfmaGeometry geo = mfma_geometry(m, batch);
+  if (geo.wave_rows != 64) geo = {64, 64};   // the two-wave split has no adaptive instantiation
+  const int spg = geo.rows / m->dp.N;
+  const int blocks = (batch + spg - 1) / spg;
+  switch (spec_equation(m, geo.rows)) {
+#define DDD_ADAPTIVE_CASE(EQ) \
+    case EQ: ddd::launch::adaptive_spec<EQ>(geo.rows, m->dp, a, blocks, stream); break;
+    DDD_ADAPTIVE_CASE(ddd::EQ_BURGERS)
+    DDD_ADAPTIVE_CASE(ddd::EQ_BURGERS_CONS)
+    DDD_ADAPTIVE_CASE(ddd::EQ_KDV)
+    DDD_ADAPTIVE_CASE(ddd::EQ_KDV_CONS)
+    DDD_ADAPTIVE_CASE(ddd::EQ_KS)
+    DDD_ADAPTIVE_CASE(ddd::EQ_KS_CONS)
+#undef DDD_ADAPTIVE_CASE
+    default:
+      if (geo.rows == 64) ddd::launch::adaptive_runtime_unit<64>(m->dp, a, blocks, stream);
+      else ddd::launch::adaptive_runtime_unit<256>(m->dp, a, blocks, stream);
+  }
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
 }
 
 int ddd_conv1d_periodic(const float* in, const float* filters, const float* bias,

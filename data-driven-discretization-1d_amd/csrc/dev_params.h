@@ -90,6 +90,19 @@ struct IntegrateArgs {
   unsigned long long* trace;   // profiling only: [blocks][kTraceSlots] s_memtime stamps
 };
 
+// ddd_integrate_adaptive_f64 (rhs_adaptive.h)
+struct AdaptiveArgs {
+  const double* times;   // [n_times] device, strictly increasing; times[0] = t0
+  int n_times;
+  double rtol, atol, max_step;
+  const double* y0;      // [batch][N]
+  double* y_out;         // [n_times][batch][N]; rows a failed sample did not reach: NaN
+  int* nfev;             // [batch]
+  int* status;           // [batch]: 0 finished, -1 step size too small, -2 attempt limit
+  int batch;
+  long long max_attempts;   // safety net against runaway samples (SciPy has none)
+};
+
 struct SubstepArgs {
   double t;
   const float* y_in;

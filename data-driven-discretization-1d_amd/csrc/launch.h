@@ -26,11 +26,18 @@ template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
                   hipStream_t stream);
 
+// adaptive RK23, one controller per sample (rhs_adaptive.h); rows: 64 or 256
+template <int kEq>
+void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int blocks,
+                   hipStream_t stream);
+
 #define DDD_DECLARE_SPEC(EQ)                                                               \
   template <> void integrate_spec<EQ>(int, bool, bool, const DevParams&, const IntegrateArgs&, \
                                       int, hipStream_t);                                       \
   template <> void substep_spec<EQ>(int, const DevParams&, const SubstepArgs&, int, int,       \
-                                    hipStream_t);
+                                    hipStream_t);                                              \
+  template <> void adaptive_spec<EQ>(int, const DevParams&, const AdaptiveArgs&, int,          \
+                                     hipStream_t);
 DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
 DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
 #undef DDD_DECLARE_SPEC
@@ -43,6 +50,14 @@ void integrate_runtime_unit(bool hoist, const DevParams& p, const IntegrateArgs&
 template <int kRows, int kWR>
 void substep_runtime_unit(const DevParams& p, const SubstepArgs& a, int blocks,
                           hipStream_t stream);
+
+// adaptive RK23 on the run-time-parameterised kernels (float64 units of the
+// 64-row-wavefront geometries)
+template <int kRows>
+void adaptive_runtime_unit(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                           hipStream_t stream);
+template <> void adaptive_runtime_unit<64>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);
+template <> void adaptive_runtime_unit<256>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);
 
 #define DDD_DECLARE_RT(ROWS, WR)                                                              \
   template <> void integrate_runtime_unit<ROWS, WR, 0>(bool, const DevParams&,               \

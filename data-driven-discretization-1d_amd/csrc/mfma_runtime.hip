@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
+#include "rhs_adaptive.h"
 #include "rhs_mfma.h"
 
 #if !defined(DDD_RT_ROWS) || !defined(DDD_RT_WR) || !defined(DDD_RT_F64)
@@ -39,6 +40,16 @@ void substep_runtime_unit<DDD_RT_ROWS, DDD_RT_WR>(const DevParams& p, const Subs
                                                   int blocks, hipStream_t stream) {
   hipLaunchKernelGGL((mfma::substep_kernel<DDD_RT_ROWS, DDD_RT_WR>), dim3(blocks),
                      dim3(DDD_RT_ROWS / DDD_RT_WR * 64), 0, stream, p, a);
+}
+#endif
+
+#if DDD_RT_F64 && DDD_RT_WR == 64
+// adaptive RK23 (float64 state): weights re-fetched per evaluation, any depth
+template <>
+void adaptive_runtime_unit<DDD_RT_ROWS>(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                                        hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::adaptive_kernel<DDD_RT_ROWS, 64, false, -1>), dim3(blocks),
+                     dim3(DDD_RT_ROWS), 0, stream, p, a);
 }
 #endif
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
+#include "rhs_adaptive.h"
 #include "rhs_mfma.h"
 
 #ifndef DDD_EQ
@@ -47,6 +48,17 @@ void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, in
   else
     hipLaunchKernelGGL((mfma::substep_multi_kernel<256, 64, DDD_EQ>), dim3(grid), dim3(256), 0,
                        stream, p, a, groups);
+}
+
+template <>
+void adaptive_spec<DDD_EQ>(int rows, const DevParams& p, const AdaptiveArgs& a, int blocks,
+                           hipStream_t stream) {
+  if (rows == 64)
+    hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ>), dim3(blocks), dim3(64), 0,
+                       stream, p, a);
+  else
+    hipLaunchKernelGGL((mfma::adaptive_kernel<256, 64, true, DDD_EQ>), dim3(blocks), dim3(256),
+                       0, stream, p, a);
 }
 
 }  // namespace launch

@@ -39,9 +39,13 @@ def weak_shard_ids(per_rank: int, rank: int):
 def gather_states(local, total: Optional[int] = None, group=None):
   """All-gather per-rank slabs [b_r, ...] into [sum b_r, ...] in rank order.
 
-  Equal slab sizes use one ``all_gather_into_tensor``; ragged slabs (total not
-  divisible by the world size) are padded to the largest slab and trimmed.
-  Works on any backend (RCCL for CUDA tensors, gloo for CPU tensors).
+  Slab sizes are never exchanged: with ``total`` every rank derives them from
+  ``shard_bounds`` (the partition all callers use); without it the slabs are
+  taken to be equal (weak sharding).  Equal slabs use ONE
+  ``all_gather_into_tensor`` and nothing else -- no pickled object collective,
+  no host synchronisation --; ragged slabs (total not divisible by the world
+  size) are padded to the largest slab and trimmed.  Works on any backend
+  (RCCL for CUDA tensors, gloo for CPU tensors).
   """
   import torch
   import torch.distributed as dist
@@ -50,8 +54,15 @@ def gather_states(local, total: Optional[int] = None, group=None):
   world = dist.get_world_size(group)
   if world == 1:
     return local
-  sizes = [None] * world
-  dist.all_gather_object(sizes, int(local.shape[0]), group=group)
+  if total is None:
+    sizes = [int(local.shape[0])] * world
+  else:
+    bounds = [shard_bounds(total, r, world) for r in range(world)]
+    sizes = [hi - lo for lo, hi in bounds]
+    mine = sizes[dist.get_rank(group)]
+    if int(local.shape[0]) != mine:
+      raise ValueError('this rank holds {} samples, shard_bounds({}, ..) assigns it {}'
+                       .format(int(local.shape[0]), total, mine))
   if len(set(sizes)) == 1:
     out = torch.empty((world * sizes[0],) + tuple(local.shape[1:]),
                       dtype=local.dtype, device=local.device)
@@ -63,7 +74,4 @@ def gather_states(local, total: Optional[int] = None, group=None):
   padded[:local.shape[0]] = local
   pieces = [torch.empty_like(padded) for _ in range(world)]
   dist.all_gather(pieces, padded, group=group)
-  out = torch.cat([p[:s] for p, s in zip(pieces, sizes)], dim=0)
-  if total is not None and out.shape[0] != total:
-    raise RuntimeError('gathered {} samples, expected {}'.format(out.shape[0], total))
-  return out
+  return torch.cat([p[:s] for p, s in zip(pieces, sizes)], dim=0)

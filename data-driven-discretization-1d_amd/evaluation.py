@@ -9,10 +9,14 @@ are reported.
 The reference integrates one sample per Beam worker with SciPy RK23 through a
 TF session.  Here ``run_integrate`` keeps that execution shape (one sample, one
 adaptive solve, HIP right-hand side) and ``run_integrate_batch`` advances all
-samples together on the GPU with the fixed-step Bogacki-Shampine scheme at
-``max_step`` -- the same trajectory whenever RK23's controller is saturated at
-max_step = 0.01 (notebooks/time-integration.ipynb); with more than one rank the
-samples are sharded and gathered (``distributed``), the analogue of
+samples together in one launch with the same adaptive RK23 -- one
+SciPy-identical step-size controller per sample on the device
+(``ddd_integrate_adaptive_f64``), so every sample gets the trajectory and the
+``num_evals`` of its own ``solve_ivp`` call whatever its stiffness.
+``adaptive=False`` selects the fixed-step Bogacki-Shampine scheme at
+``max_step`` instead (equal only while the controller is saturated, as in
+notebooks/time-integration.ipynb).  With more than one rank the samples are
+sharded and gathered (``distributed``), the analogue of
 ``beam.CombineGlobally(ConcatCombineFn('sample'))`` (run_evaluation.py:218).
 
 Arrays are plain NumPy: ``y_model`` [sample, time, x_low], ``y_exact``
@@ -126,8 +130,11 @@ def run_integrate(seed_and_initial_condition, model: model_lib.LearnedStencilMod
 def run_integrate_batch(model: model_lib.LearnedStencilModel, hparams,
                         initial_conditions: np.ndarray, times: np.ndarray,
                         warmup: float = 0, max_step: float = 0.01,
-                        scheme: str = 'bs3', first_seed: int = 0):
-  """All samples of this rank together, fixed step ``max_step``.
+                        scheme: str = 'bs3', first_seed: int = 0,
+                        adaptive: Optional[bool] = None):
+  """All samples of this rank together: adaptive RK23 with one controller per
+  sample (``adaptive=True``; the default for scheme='bs3' whenever the model
+  runs on the MFMA kernels), or the fixed step ``max_step`` with ``scheme``.
 
   Sample i uses random_seed = first_seed + i for its forcing, like the
   reference's per-seed equations.  With torch.distributed initialised the
@@ -143,15 +150,21 @@ def run_integrate_batch(model: model_lib.LearnedStencilModel, hparams,
   if model.equation.has_time_dependent_forcing and hi > lo:
     eqs = [equations_lib.from_hparams(hparams, random_seed=s)[1] for s in seeds]
     forcing = model_lib.forcing_from_equations(eqs)
+  if adaptive is None:   # RK23's own tableau on a model the device controller supports
+    adaptive = scheme == 'bs3' and model.kernel_name.startswith('mfma')
   if hi > lo:
     ds = integrate.integrate_batch(model, initial_conditions[lo:hi], warmup + times,
-                                   dt=max_step, scheme=scheme, forcing=forcing)
+                                   dt=max_step, scheme=scheme, forcing=forcing,
+                                   adaptive=adaptive)
     y_local = _data(ds, 'y')
-    evals = int(np.asarray(_coord(ds, 'num_evals')))
+    evals_local = np.broadcast_to(np.asarray(_coord(ds, 'num_evals'), dtype=np.int64),
+                                  (hi - lo,)).copy()
   else:
-    y_local = np.zeros((0, len(times), initial_conditions.shape[1]), np.float32)
-    evals = 0
+    dtype = np.float64 if adaptive else np.float32
+    y_local = np.zeros((0, len(times), initial_conditions.shape[1]), dtype)
+    evals_local = np.zeros(0, np.int64)
   y = y_local
+  num_evals = evals_local
   if world > 1:
     import torch
     import torch.distributed as dist
@@ -160,8 +173,10 @@ def run_integrate_batch(model: model_lib.LearnedStencilModel, hparams,
     device = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
     y = distributed.gather_states(torch.from_numpy(np.ascontiguousarray(y_local)).to(device),
                                   total).cpu().numpy()
+    num_evals = distributed.gather_states(
+        torch.from_numpy(evals_local).to(device), total).cpu().numpy()
   return dict(y=y, time=warmup + times, x=model.equation.grid.solution_x,
-              num_evals=np.full(total, evals), sample=first_seed + np.arange(total))
+              num_evals=num_evals, sample=first_seed + np.arange(total))
 
 
 def evaluate(model: model_lib.LearnedStencilModel, hparams, y_exact: np.ndarray,

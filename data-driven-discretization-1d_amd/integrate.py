@@ -423,16 +423,41 @@ def integrate_model_from_warm_start(checkpoint_dir: Optional[str],
 def integrate_batch(device_model, y0, times: np.ndarray, dt: float = 0.01,
                     scheme: str = 'bs3', forcing: Optional[dict] = None,
                     launch_mode: str = 'persistent',
-                    state_dtype: str = 'float32'):
-  """All samples at once on the GPU with a fixed step.
+                    state_dtype: str = 'float32', adaptive: bool = False,
+                    rtol: float = 1e-3, atol: float = 1e-6):
+  """All samples at once on the GPU; sample b starts from y0[b].
 
-  ``times`` must be uniformly spaced multiples of ``dt`` starting at times[0];
-  sample b starts from y0[b].  With scheme='bs3' and dt = 0.01 this is what
-  the reference's solve_ivp(RK23, max_step=0.01) computes whenever its step
-  controller sits at max_step (the regime of notebooks/time-integration.ipynb).
-  Returns a Dataset with y [sample, time, x] and num_evals.
+  ``adaptive=True``: the batched form of ``odeint`` -- SciPy's RK23 with
+  ``max_step = dt`` and one step-size controller per sample on the device
+  (``ddd_integrate_adaptive_f64``): each sample's trajectory and ``num_evals``
+  are what the reference's per-sample ``solve_ivp`` call produces
+  (integrate.py:143-169, run_evaluation.py:152-174); ``times`` may be any
+  increasing sequence, rows a diverged sample did not reach are NaN.
+
+  ``adaptive=False``: fixed step ``dt`` (``times`` uniformly spaced multiples
+  of it).  With scheme='bs3' this equals the adaptive result only while RK23's
+  controller sits at max_step (smooth Burgers runs); it is the training-time
+  ``model.integrate_ode`` shape and the throughput path.
+
+  Returns a Dataset with y [sample, time, x] and num_evals (per sample when
+  adaptive).
   """
   times = np.asarray(times, dtype=np.float64)
+  if forcing is not None:
+    device_model.set_forcing(forcing)
+  if adaptive:
+    traj, nfev, status = device_model.integrate_adaptive(
+        y0, times, rtol=rtol, atol=atol, max_step=dt)
+    y = traj.permute(1, 0, 2).contiguous().cpu().numpy()
+    status = status.cpu().numpy()
+    if (status != 0).any():
+      logging.info('%d trajectories stopped early (NaN rows)', int((status != 0).sum()))
+    return _make_dataset(
+        data_vars={'y': (('sample', 'time', 'x'), y)},
+        coords={'time': times, 'x': device_model.equation.grid.solution_x,
+                'sample': np.arange(y.shape[0]),
+                'num_evals': ('sample', nfev.cpu().numpy().astype(np.int64)),
+                'status': ('sample', status)})
   spacing = np.diff(times)
   if len(times) < 2 or not np.allclose(spacing, spacing[0]):
     raise ValueError('times must be uniformly spaced')
@@ -440,8 +465,6 @@ def integrate_batch(device_model, y0, times: np.ndarray, dt: float = 0.01,
   if save_every < 1 or abs(save_every * dt - spacing[0]) > 1e-9 * max(1, spacing[0]):
     raise ValueError('output spacing {} is not a multiple of dt {}'
                      .format(spacing[0], dt))
-  if forcing is not None:
-    device_model.set_forcing(forcing)
   num_steps = save_every * (len(times) - 1)
   traj = device_model.integrate_fixed(
       y0, num_steps, dt=dt, t0=float(times[0]), scheme=scheme,

@@ -315,6 +315,36 @@ class _DeviceModel(object):
     return out
 
 
+  def integrate_adaptive(self, y0, times, rtol: float = 1e-3, atol: float = 1e-6,
+                         max_step: float = 0.01, max_attempts: int = 0):
+    """SciPy RK23 with one step-size controller per sample, on the device.
+
+    The batched form of ``integrate.odeint`` (integrate.py:143-169): every
+    sample b is advanced from y0[b] exactly as
+    ``solve_ivp(rhs_b, (times[0], times[-1]), y0[b], t_eval=times,
+    max_step=max_step, method='RK23')`` would, in one launch.  Returns
+    ``(y [time, batch, x] float64, nfev [batch] int32, status [batch] int32)``
+    as device tensors; status 0 = finished, -1 = step size too small (the
+    sample's remaining rows are NaN), -2 = attempt limit.
+    """
+    lib = _lib.load_library()
+    torch, y0 = self._check_state(y0, _lib._torch().float64)
+    times = np.ascontiguousarray(np.asarray(times, dtype=np.float64))
+    if times.ndim != 1 or times.size < 1:
+      raise ValueError('times must be a non-empty 1-D array')
+    batch = y0.shape[0]
+    out = torch.empty((times.size,) + tuple(y0.shape), dtype=torch.float64,
+                      device=y0.device)
+    nfev = torch.zeros(batch, dtype=torch.int32, device=y0.device)
+    status = torch.zeros(batch, dtype=torch.int32, device=y0.device)
+    _lib.check(lib.ddd_integrate_adaptive_f64(
+        self._handle, times.ctypes.data_as(_lib._D), int(times.size),
+        float(rtol), float(atol), float(max_step), int(max_attempts),
+        y0.data_ptr(), out.data_ptr(), nfev.data_ptr(), status.data_ptr(),
+        batch, _lib.current_stream()))
+    return out, nfev, status
+
+
 class LearnedStencilModel(_DeviceModel):
   """Conv-net coefficient predictor for one equation + hparams.
 

@@ -245,6 +245,37 @@ int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
                             int n_steps, int save_every, const double* y0,
                             double* y_out, int batch, void* stream);
 
+/* Replaces: integrate.odeint (integrate.py:143-169) =
+ * scipy.integrate.solve_ivp(differentiator, (times[0], times[-1]), y0,
+ * t_eval=times, max_step=0.01, method='RK23'), as scripts/run_evaluation.py
+ * (:152-174) calls it once per sample -- for the whole batch in ONE launch,
+ * with one SciPy-identical step-size controller per sample on the device:
+ * Bogacki-Shampine 3(2) with FSAL, select_initial_step, error norm
+ * RMS(err / (atol + rtol * max(|y|, |y_new|))), step factor
+ * clip(0.9 * norm^(-1/3), 0.2, 10) without growth after a rejection, steps
+ * clamped to [10 ulp(t), max_step], cubic dense output at `times`.  State,
+ * controller and dense output in float64 (SciPy's), right-hand side in float32
+ * fed float32(y), float32(t) (the TF placeholders, integrate.py:57-60).
+ *   times  HOST [n_times], finite, strictly increasing; times[0] = t0 (the
+ *          reference's rule: defaults rtol 1e-3, atol 1e-6, max_step 0.01)
+ *   y0     [batch][N] float64;  y_out [n_times][batch][N] float64 (row 0 = y0)
+ *   nfev   [batch] int32: right-hand-side evaluations of each sample
+ *          (solve_ivp's sol.nfev)
+ *   status [batch] int32: 0 = reached times[n_times-1]; -1 = step size fell
+ *          below 10 ulp(t) (SciPy's "Required step size is less than spacing
+ *          between numbers", sol.status -1); -2 = `max_attempts` steps tried
+ *          (a safety net SciPy does not have; <= 0 selects a default of 1000x
+ *          the attempts of a run at max_step).  Rows a failed sample did not
+ *          reach are NaN, as integrate.odeint pads them (integrate.py:161-167).
+ * MFMA-path models only (ddd_kernel_name "mfma_f32_*"); others return
+ * DDD_ERR_UNSUPPORTED and keep the one-sample SciPy route over
+ * ddd_time_derivative. */
+int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
+                               int n_times, double rtol, double atol,
+                               double max_step, long long max_attempts,
+                               const double* y0, double* y_out, int32_t* nfev,
+                               int32_t* status, int batch, void* stream);
+
 /* Float64 forms for spectral models (ddd_spectral_create).
  * ddd_time_derivative_f64 replaces SpectralDifferentiator.__call__
  * (integrate.py:113-121) without finalize_time_derivative, batched;

@@ -468,6 +468,122 @@ def odeint_rk23(spec, y0, times, forcing=None, method='RK23'):
   return y, sol.nfev
 
 
+# SciPy's RK23 (scipy.integrate._ivp.rk.RK23 / RungeKutta / rk_step,
+# _ivp.common.select_initial_step, _ivp.ivp.solve_ivp) restated statement by
+# statement: the algorithm `ddd_integrate_adaptive_f64` runs on the device, one
+# controller per sample.  SciPy is a third-party dependency of the reference
+# (setup.py:25, unpinned; call site integrate.py:154-155); this restatement is
+# pinned against the installed SciPy itself (tests/test_cpu_oracle.py:
+# identical nfev, trajectories equal to float64 rounding).
+RK23_C = (0.0, 0.5, 0.75)
+RK23_A = ((0.0, 0.0, 0.0), (0.5, 0.0, 0.0), (0.0, 0.75, 0.0))
+RK23_B = (2 / 9, 1 / 3, 4 / 9)
+RK23_E = (5 / 72, -1 / 12, -1 / 9, 1 / 8)
+RK23_P = ((1, -4 / 3, 5 / 9), (0, 1, -2 / 3), (0, 4 / 3, -8 / 9), (0, -1, 1))
+RK_SAFETY, RK_MIN_FACTOR, RK_MAX_FACTOR = 0.9, 0.2, 10.0
+
+
+def _rms(x):
+  """_ivp.common.norm: np.linalg.norm(x) / x.size ** 0.5."""
+  return np.sqrt(np.sum(x * x)) / x.size ** 0.5
+
+
+def rk23_adaptive(fun, y0, times, rtol=1e-3, atol=1e-6, max_step=0.01):
+  """solve_ivp(fun, (times[0], times[-1]), y0, t_eval=times, method='RK23',
+  max_step=max_step) for ONE sample; ``fun(t, y)`` returns float32.
+
+  Returns (y [time, x] float64 with NaN rows past a failure, nfev, status)
+  where status 0 = reached times[-1], -1 = step size fell below the spacing
+  of floating point numbers (SciPy's TOO_SMALL_STEP).
+  """
+  times = np.asarray(times, dtype=np.float64)
+  t, t_bound = float(times[0]), float(times[-1])
+  y = np.asarray(y0, dtype=np.float64).copy()
+  out = np.full((len(times), y.size), np.nan)
+  # RungeKutta.__init__: f = fun(t0, y0); select_initial_step (order 2)
+  f = np.asarray(fun(t, y))
+  nfev = 1
+  interval = abs(t_bound - t)
+  if interval == 0.0:
+    out[0] = y
+    return out, nfev, 0
+  scale = atol + np.abs(y) * rtol
+  d0 = _rms(y / scale)
+  d1 = _rms(f / scale)
+  h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+  h0 = h0 if not interval < h0 else interval
+  f1 = np.asarray(fun(t + h0, y + h0 * f))
+  nfev += 1
+  d2 = _rms((f1 - f) / scale) / h0          # float32 difference, as SciPy forms it
+  if d1 <= 1e-15 and d2 <= 1e-15:
+    h1 = 1e-6 if not h0 * 1e-3 > 1e-6 else h0 * 1e-3
+  else:
+    h1 = (0.01 / (d1 if not d2 > d1 else d2)) ** (1 / 3)
+  h_abs = 100 * h0
+  for cand in (h1, interval, max_step):
+    if cand < h_abs:
+      h_abs = cand
+  ti = 0
+  k = [None] * 4
+  while True:
+    # RungeKutta._step_impl
+    min_step = 10 * abs(np.nextafter(t, np.inf) - t)
+    if h_abs > max_step:
+      h_abs = max_step
+    elif h_abs < min_step:
+      h_abs = min_step
+    rejected = False
+    while True:
+      if h_abs < min_step:
+        return out, nfev, -1
+      t_new = t + h_abs
+      if t_new - t_bound > 0:
+        t_new = t_bound
+      h = t_new - t
+      h_abs = abs(h)
+      # rk_step
+      k[0] = f.astype(np.float64)
+      k[1] = np.asarray(fun(t + RK23_C[1] * h, y + (k[0] * RK23_A[1][0]) * h),
+                        dtype=np.float64)
+      k[2] = np.asarray(fun(t + RK23_C[2] * h,
+                            y + (k[0] * RK23_A[2][0] + k[1] * RK23_A[2][1]) * h),
+                        dtype=np.float64)
+      y_new = y + h * ((k[0] * RK23_B[0] + k[1] * RK23_B[1]) + k[2] * RK23_B[2])
+      f_new = np.asarray(fun(t + h, y_new))
+      k[3] = f_new.astype(np.float64)
+      nfev += 3
+      scale = atol + np.maximum(np.abs(y), np.abs(y_new)) * rtol
+      err = (((k[0] * RK23_E[0] + k[1] * RK23_E[1]) + k[2] * RK23_E[2])
+             + k[3] * RK23_E[3]) * h
+      error_norm = _rms(err / scale)
+      if error_norm < 1:
+        if error_norm == 0:
+          factor = RK_MAX_FACTOR
+        else:
+          factor = RK_SAFETY * error_norm ** (-1 / 3)
+          factor = RK_MAX_FACTOR if not factor < RK_MAX_FACTOR else factor
+        if rejected:
+          factor = 1 if not factor < 1 else factor
+        h_abs *= factor
+        break
+      factor = RK_SAFETY * error_norm ** (-1 / 3)
+      h_abs *= RK_MIN_FACTOR if not factor > RK_MIN_FACTOR else factor
+      rejected = True
+    t_old, y_old = t, y
+    t, y, f = t_new, y_new, f_new
+    # solve_ivp: dense output (RkDenseOutput) at every t_eval <= t
+    while ti < len(times) and times[ti] <= t:
+      x = (times[ti] - t_old) / h
+      p1 = x
+      p2 = p1 * x
+      p3 = p2 * x
+      q = [sum(k[s] * RK23_P[s][j] for s in range(4)) for j in range(3)]
+      out[ti] = h * ((q[0] * p1 + q[1] * p2) + q[2] * p3) + y_old
+      ti += 1
+    if t - t_bound >= 0:
+      return out, nfev, 0
+
+
 SCHEME_EULER = 0
 SCHEME_MIDPOINT = 1
 SCHEME_BS3 = 2

@@ -189,3 +189,65 @@ def test_midpoint_is_second_order_on_linear_problem():
   # halving the step divides the error by ~2^order (float32 RHS noise limits
   # the high-order ones, so only require monotone improvement there)
   assert errs[0][1] > 1.7 and errs[1][1] > 3.0
+
+
+# ---------------------------------------------------------------------------
+# The adaptive controller the device runs (rhs_adaptive.h) = oracle.rk23_adaptive,
+# pinned against the installed SciPy (the reference's integrator, integrate.py:154)
+# ---------------------------------------------------------------------------
+def _toy_rhs(n, seed, stiffness):
+  """Contracting (so that one-ulp differences do not amplify), stiff (so that the
+  controller is stability-limited and rejects) float32 right-hand side."""
+  rs = np.random.RandomState(seed)
+  q, _ = np.linalg.qr(rs.randn(n, n))
+  lam = np.linspace(1.0, stiffness, n)
+  a = ((q * lam) @ q.T).astype(np.float32)
+
+  def fun(t, y):
+    y32 = np.asarray(y, np.float32)
+    return (-(a @ y32) - np.float32(0.5) * y32 ** 3 + np.float32(np.sin(7 * t))).astype(np.float32)
+  return fun
+
+
+@pytest.mark.parametrize('stiffness,max_step', [(3.0, 0.01), (3.0, np.inf), (300.0, np.inf),
+                                               (3000.0, 0.01)])
+def test_rk23_restatement_equals_scipy(stiffness, max_step):
+  """Saturated steps, controller-limited steps, rejections: identical nfev and
+  float64-rounding-equal dense output at times that are not step boundaries."""
+  import scipy.integrate
+  times = np.array([0.0, 0.0371, 0.2, 0.55, 1.0])
+  rejected_somewhere = False
+  for seed in range(4):
+    fun = _toy_rhs(16, seed, stiffness)
+    y0 = np.random.RandomState(seed + 10).randn(16).astype(np.float32).astype(np.float64)
+    sol = scipy.integrate.solve_ivp(fun, (times[0], times[-1]), y0, t_eval=times,
+                                    max_step=max_step, method='RK23')
+    y, nfev, status = oracle.rk23_adaptive(fun, y0, times, max_step=max_step)
+    assert status == 0 and sol.status == 0
+    assert nfev == sol.nfev
+    # (not bitwise: BLAS sums the error norm in another order, and one ulp of a
+    # step size moves a float32 rounding of the right-hand side's input)
+    np.testing.assert_allclose(y, sol.y.T, rtol=1e-9, atol=1e-10)
+    rejected_somewhere |= stiffness < 100 or (nfev - 2) // 3 > 150
+  assert rejected_somewhere   # the stiff cases are limited by stability, not by max_step
+
+
+def test_rk23_restatement_failure_path():
+  """Finite-time blow-up: SciPy gives up when the step drops under 10 ulp(t)
+  (status -1); the rows not reached are NaN (integrate.py:161-167)."""
+  import scipy.integrate
+
+  def fun(t, y):
+    y32 = np.asarray(y, np.float32)
+    return (y32 * y32).astype(np.float32)   # y' = y^2 blows up at t = 1 / y0
+  times = np.linspace(0.0, 1.0, 6)
+  y0 = np.array([2.5, 3.0])
+  sol = scipy.integrate.solve_ivp(fun, (0.0, 1.0), y0, t_eval=times, max_step=0.01,
+                                  method='RK23')
+  y, nfev, status = oracle.rk23_adaptive(fun, y0, times)
+  assert sol.status == -1 and status == -1
+  assert nfev == sol.nfev
+  reached = sol.y.shape[1]
+  assert 0 < reached < len(times)
+  np.testing.assert_allclose(y[:reached], sol.y.T, rtol=1e-9)
+  assert np.isnan(y[reached:]).all()
