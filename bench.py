@@ -39,6 +39,18 @@ With N > 1 every rank integrates its own shard of the ensemble (weak scaling,
 no communication during stepping) and the final states are all-gathered over
 RCCL inside the timed region (BASELINE.json config 5's "final gather").
 
+At N = 1 the same run also measures, each over its own >= --config-timed-ms
+timed region and each with its roofline fraction, the rest of the contract
+(reported under "configs"): BASELINE configs[2] (KdV N=64 B=4096) and
+configs[3] (KS N=256 B=8192), the headline workload with ONE FUSED LAUNCH PER
+RK SUBSTEP (north_star's literal structure), the HBM-bound fixed-stencil
+streaming kernel (GB/s against the HBM peak), the batch-1
+`SavedModelDifferentiator.__call__` latency a SciPy caller sees, and the
+on-device adaptive RK23 (the reference's production integrator, one controller
+per sample).  With N > 1 the default shard is 8192 samples per GPU
+(BASELINE configs[4]: 65 536 / 8); rank 0 also reports every rank's kernel
+time and the isolated cost of the final gather.
+
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline and
 cpu_baseline definitions.
 """
@@ -63,12 +75,18 @@ PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
 TRAFFIC_TABLES = ('r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
 
 
+CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'stream_fixed',
+                'differentiator_b1', 'adaptive_rk23')
+
+
 def parse_args(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=1000)
   ap.add_argument('--warmup', type=int, default=100)
-  ap.add_argument('--batch', type=int, default=4096, help='samples per GPU')
+  ap.add_argument('--batch', type=int, default=None,
+                  help='samples per GPU; default 4096 at --gpus 1 (north_star target), '
+                       '8192 at --gpus > 1 (BASELINE configs[4]: 65 536 / 8)')
   ap.add_argument('--secondary-batch', type=int, default=1024,
                   help='second batch size measured in the same run at N=1 '
                        '(BASELINE.json configs[1]); 0 disables')
@@ -88,8 +106,13 @@ def parse_args(argv=None):
                   choices=['auto', 'mfma', 'mfma64', 'mfma64w32', 'mfma256', 'generic'])
   ap.add_argument('--preheat-ms', type=float, default=300.0,
                   help='run the timed kernel this long before --warmup (0 disables)')
-  ap.add_argument('--min-timed-ms', type=float, default=40.0,
+  ap.add_argument('--min-timed-ms', type=float, default=1000.0,
                   help='repeat the K-step job until the timed region lasts this long')
+  ap.add_argument('--configs', default='all',
+                  help="comma list of the extra measurements at --gpus 1 ('all', 'none', or of "
+                       + ', '.join(CONFIG_NAMES) + ')')
+  ap.add_argument('--config-timed-ms', type=float, default=600.0,
+                  help='minimum timed region of each extra measurement')
   ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                   help='collective backend for --gpus > 1: nccl = RCCL over xGMI (the '
                        'measured configuration); gloo stages the gather through host '
@@ -100,10 +123,17 @@ def parse_args(argv=None):
                        'logged to stderr, never set in a headline run')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
-  return ap.parse_args(argv)
+  args = ap.parse_args(argv)
+  if args.batch is None:
+    args.batch = 4096 if args.gpus == 1 else 8192
+  return args
 
 
-def build_workload(args, rank, batch):
+def build_workload(args, rank, batch, unique=None):
+  """Model + per-sample forcing + random-phase initial conditions for `batch`
+  samples of this rank.  `unique`: draw only that many distinct samples and
+  tile them (the 262 144-sample streaming config; sample content does not
+  change the work)."""
   import ddd1d_amd
   from ddd1d_amd import equations, model as model_lib
   rf = 8
@@ -119,9 +149,9 @@ def build_workload(args, rank, batch):
   model.set_kernel(args.kernel)
   # sample ids are global: rank r owns ids [r*batch, (r+1)*batch)
   from ddd1d_amd import distributed
-  seeds = distributed.weak_shard_ids(batch, rank)
+  drawn = batch if unique is None else min(unique, batch)
+  seeds = list(distributed.weak_shard_ids(batch, rank))[:drawn]
   forcing = model_lib.batched_forcing_parameters(seeds, nparams=20)
-  model.set_forcing(forcing)
   ic = model_lib.batched_forcing_parameters(
       [s + (1 << 20) for s in seeds], nparams=10)
   x = eq.grid.reference_x
@@ -129,6 +159,11 @@ def build_workload(args, rank, batch):
       2 * np.pi * ic['k'][..., None] * x / eq.grid.period + ic['phi'][..., None]),
                  axis=1)
   y0 = eq.grid.resample(waves).astype(np.float32)
+  if drawn < batch:
+    reps = -(-batch // drawn)
+    y0 = np.tile(y0, (reps, 1))[:batch]
+    forcing = {k: np.tile(v, (reps, 1))[:batch] for k, v in forcing.items()}
+  model.set_forcing(forcing)
   return eq, model, forcing, y0
 
 
@@ -381,13 +416,36 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evts)
   clocks = sampler.stop(wall0, wall1) if sampler is not None else None
 
+  per_rank = None
   if world > 1:
-    t = torch.tensor([wall, kernel_ms], dtype=torch.float64, device='cpu' if host else 'cuda')
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall, kernel_ms = float(t[0]), float(t[1])
+    # one line must explain a < N x result: every rank's own wall / kernel time,
+    # and the final gather timed on its own (outside the timed region, after it)
+    gather_ms = []
+    for _ in range(5):
+      barrier()
+      g0 = time.perf_counter()
+      gather_final(0)
+      wait_slot(0)
+      torch.cuda.synchronize()
+      gather_ms.append((time.perf_counter() - g0) * 1e3)
+    mine = torch.tensor([wall * 1e3, kernel_ms, min(gather_ms)], dtype=torch.float64,
+                        device='cpu' if host else 'cuda')
+    everyone = torch.empty(world * 3, dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(everyone, mine)
+    table = everyone.cpu().reshape(world, 3)
+    per_rank = {'wall_ms': [float(v) for v in table[:, 0]],
+                'kernel_ms': [float(v) for v in table[:, 1]],
+                'gather_ms_isolated': [float(v) for v in table[:, 2]],
+                'gather_bytes_per_rank': int(finals[0][0].numel() * finals[0].element_size())}
+    wall, kernel_ms = float(table[:, 0].max()) * 1e-3, float(table[:, 1].max())
   finite = bool(torch.isfinite(finals[0]).all())
+  if not finite:
+    sys.stderr.write('bench.py: WARNING: the state is not finite after the timed run '
+                     '(batch {}): its throughput is reported with "finite": false and '
+                     'must not be quoted\n'.format(batch))
   return dict(wall=wall, kernel_ms=kernel_ms, reps=reps, finite=finite,
-              preheat_ms=heated, preheat_launches=heat_launches, clocks=clocks)
+              preheat_ms=heated, preheat_launches=heat_launches, clocks=clocks,
+              per_rank=per_rank)
 
 
 def summarize(args, eq, model, m, world, n, batch, stages):
@@ -406,7 +464,7 @@ def summarize(args, eq, model, m, world, n, batch, stages):
   achieved_tflops = flops_per_launch / launch_s / 1e12
   achieved_gbps = bytes_per_launch / launch_s / 1e9
   compute_bound = not args.baseline_stencils
-  traffic, traffic_source = measured_traffic(
+  traffic, traffic_source, traffic_command = measured_traffic(
       type(eq).__name__, n, batch, args.launch_mode, args.baseline_stencils,
       state_dtype=args.state_dtype)
   roofline = {
@@ -417,7 +475,8 @@ def summarize(args, eq, model, m, world, n, batch, stages):
       'frac': (achieved_tflops / PEAK_FP32_TFLOPS if compute_bound
                else achieved_gbps / PEAK_HBM_GBPS),
       'traffic': traffic,
-      'traffic_source': traffic_source,
+      'traffic_source': traffic_source,     # committed rocprofv3 --pmc passes of this
+      'traffic_command': traffic_command,   # configuration (bench.py cannot read counters)
       'kernel_ms_per_launch': m['kernel_ms'] / launches,
       'launches': launches,
       'hbm_gbps': achieved_gbps,
@@ -430,6 +489,164 @@ def summarize(args, eq, model, m, world, n, batch, stages):
       'ms_per_step': m['wall'] * 1e3 / steps_timed,
       'roofline': roofline,
   }
+
+
+def _variant(args, **overrides):
+  out = argparse.Namespace(**vars(args))
+  for k, v in overrides.items():
+    setattr(out, k, v)
+  return out
+
+
+def _fixed_step_config(args, lib, world, name, note, batch, unique=None, **overrides):
+  """One extra fixed-step measurement through the same measure()/summarize()."""
+  import ddd1d_amd
+  a = _variant(args, min_timed_ms=args.config_timed_ms, preheat_ms=min(args.preheat_ms, 150.0),
+               warmup=min(args.warmup, 20), **overrides)
+  eq, model, _, y0 = build_workload(a, 0, batch, unique=unique)
+  n = eq.grid.solution_num_points
+  stages = lib.ddd_scheme_stages(ddd1d_amd._lib.SCHEMES[a.scheme])
+  m = measure(a, model, y0, world, n, batch)
+  s = summarize(a, eq, model, m, world, n, batch, stages)
+  r = s['roofline']
+  out = {
+      'workload': note, 'equation': type(eq).__name__, 'num_points': n, 'batch': batch,
+      'steps': a.steps, 'reps': m['reps'], 'scheme': a.scheme, 'launch_mode': a.launch_mode,
+      'kernel': model.kernel_name, 'value': s['value'], 'unit': 'grid-point-steps/s',
+      'ms_per_step': s['ms_per_step'], 'timed_wall_ms': m['wall'] * 1e3,
+      'bound': r['bound'], 'achieved': r['achieved'], 'peak': r['peak'],
+      'roofline_unit': r['unit'], 'frac': r['frac'],
+      'kernel_ms_per_launch': r['kernel_ms_per_launch'], 'launches': r['launches'],
+      'traffic': r['traffic'], 'traffic_source': r['traffic_source'], 'finite': m['finite'],
+  }
+  model.close()
+  return name, out
+
+
+def _differentiator_config(args):
+  """Batch-1 `SavedModelDifferentiator.__call__(t, y)` (integrate.py:48-71) as
+  SciPy calls it: host float64 array in, host array out, one launch per call.
+  The reference logs 2.0-4.3 ms per evaluation of this seam."""
+  import torch
+  from ddd1d_amd import integrate
+  a = _variant(args)
+  eq, model, _, y0 = build_workload(a, 0, 1)
+  diff = integrate.SavedModelDifferentiator(None, eq, model.hparams, model=model)
+  y = y0[0].astype(np.float64)
+  for i in range(200):
+    diff(1e-3 * i, y)
+  torch.cuda.synchronize()
+  calls, elapsed = 0, 0.0
+  while elapsed * 1e3 < args.config_timed_ms:
+    t0 = time.perf_counter()
+    for i in range(500):
+      out = diff(1e-3 * i, y)
+    elapsed += time.perf_counter() - t0
+    calls += 500
+  us = elapsed / calls * 1e6
+  n = eq.grid.solution_num_points
+  flops = 2.0 * diff.model.fma_per_point * n
+  result = {
+      'workload': 'Differentiator.__call__(t, y[{}]) -> dy/dt, batch 1, host arrays in and '
+                  'out (H2D + one fused launch + D2H per call), {} calls'.format(n, calls),
+      'value': us, 'unit': 'us/evaluation', 'higher_is_better': False,
+      'evaluations_per_s': 1e6 / us, 'kernel': diff.model.kernel_name,
+      'bound': 'latency', 'fp32_tflops': flops / (us * 1e-6) / 1e12,
+      'frac': flops / (us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS,
+      'reference_ms_per_evaluation': [2.0, 4.3], 'finite': bool(np.isfinite(out).all()),
+  }
+  diff.model.close()
+  return 'differentiator_b1', result
+
+
+def _adaptive_config(args):
+  """`ddd_integrate_adaptive_f64`: the reference's production integrator
+  (solve_ivp RK23, max_step 0.01, integrate.py:143-169) for the whole batch in
+  one launch, one controller per sample; float64 state, float32 right-hand side."""
+  import torch
+  a = _variant(args)
+  batch = 4096
+  eq, model, _, y0 = build_workload(a, 0, batch)
+  n = eq.grid.solution_num_points
+  times = np.linspace(0.0, 1.0, 11)
+  y0d = torch.from_numpy(y0.astype(np.float64)).cuda()
+  model.integrate_adaptive(y0d, times)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  kernel_ms, launches = 0.0, 0
+  wall0 = time.perf_counter()
+  while kernel_ms < args.config_timed_ms:
+    e0.record()
+    y, nfev, status = model.integrate_adaptive(y0d, times)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms += e0.elapsed_time(e1)
+    launches += 1
+  wall = time.perf_counter() - wall0
+  nfev = nfev.cpu().numpy().astype(np.int64)
+  evals = float(nfev.sum()) * n              # grid-point-evaluations per launch
+  steps = float(((nfev - 2) // 3).sum()) * n   # grid-point-steps (attempted RK23 steps)
+  tflops = 2.0 * model.fma_per_point * evals * launches / (kernel_ms * 1e-3) / 1e12
+  result = {
+      'workload': 'Burgers N={} conv-net stencils, batch {}, solve_ivp-RK23 semantics per '
+                  'sample (rtol 1e-3, atol 1e-6, max_step 0.01), t in [0, 1], 11 output '
+                  'times, {} launches'.format(n, batch, launches),
+      'value': evals * launches / (kernel_ms * 1e-3), 'unit': 'grid-point-evaluations/s',
+      'grid_point_steps_per_s': steps * launches / (kernel_ms * 1e-3),
+      'nfev_min': int(nfev.min()), 'nfev_max': int(nfev.max()),
+      'samples_finished': int((status.cpu().numpy() == 0).sum()),
+      'kernel_ms_per_launch': kernel_ms / launches, 'timed_wall_ms': wall * 1e3,
+      'kernel': model.kernel_name, 'state_dtype': 'float64',
+      'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP32_TFLOPS,
+      'roofline_unit': 'TFLOP/s', 'frac': tflops / PEAK_FP32_TFLOPS,
+      'finite': bool(torch.isfinite(y).all()),
+  }
+  model.close()
+  return 'adaptive_rk23', result
+
+
+def extra_configs(args, lib, world):
+  """The rest of the contract, measured in the same run at N = 1."""
+  wanted = (CONFIG_NAMES if args.configs == 'all' else
+            () if args.configs == 'none' else tuple(args.configs.split(',')))
+  unknown = [w for w in wanted if w not in CONFIG_NAMES]
+  if unknown:
+    raise SystemExit('unknown --configs entries: {}'.format(unknown))
+  base = dict(equation='burgers', num_points=64, non_conservative=False,
+              baseline_stencils=False, kernel='auto', scheme='midpoint',
+              launch_mode='persistent', state_dtype='float32')
+  out = {}
+  for name in wanted:
+    if name == 'kdv_n64_b4096':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'BASELINE.json configs[2]: KdV N=64, conv-net stencils, '
+          'batch 4096, midpoint at the equation time step', 4096,
+          **dict(base, equation='kdv', steps=1000))
+    elif name == 'ks_n256_b8192':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'BASELINE.json configs[3]: KS N=256, conv-net stencils, '
+          'batch 8192, midpoint at the equation time step (400-step jobs; the 10k-step '
+          'horizon is one longer launch of the same kernel)', 8192, unique=1024,
+          **dict(base, equation='ks', num_points=256, steps=400))
+    elif name == 'burgers_per_substep':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the headline workload with ONE FUSED LAUNCH PER RK '
+          'SUBSTEP (north_star structure; state through HBM every substep)', 4096,
+          **dict(base, launch_mode='per_substep', steps=200))
+    elif name == 'stream_fixed':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '
+          'KdV N=64 batch 262144, one launch per substep: the HBM-bound kernel of the path',
+          262144, unique=4096,
+          **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_substep',
+                 steps=200))
+    elif name == 'differentiator_b1':
+      key, val = _differentiator_config(_variant(args, **base))
+    else:
+      key, val = _adaptive_config(_variant(args, **base))
+    out[key] = val
+  return out
+
 
 
 def relaunch_under_torchrun(args):
@@ -494,6 +711,10 @@ def main():
         'kernel': model2.kernel_name, 'finite': m2['finite'],
     }
 
+  configs = None
+  if world == 1 and args.configs != 'none':
+    configs = extra_configs(args, lib, world)
+
   if rank == 0:
     s = summarize(args, eq, model, m, world, n, batch, stages)
     dtype = 'f32' if args.state_dtype == 'float32' else 'f32 rhs / f64 state'
@@ -512,11 +733,17 @@ def main():
         'dtype': dtype,
         'data': 'synthetic',
         'config': {
-            'workload': '{} N={} {} learned-stencil ensemble, batch {}/GPU, '
+            'workload': '{} N={} {} learned-stencil ensemble, batch {}/GPU{}, '
                         '{} steps, {} dt={:g}'.format(
                             args.equation, n,
                             'fixed-stencil' if args.baseline_stencils else 'conv-net',
-                            batch, args.steps, args.scheme, dt),
+                            batch,
+                            ' (BASELINE configs[4]: {} samples weak-sharded over {} GPUs, '
+                            'final states all-gathered over RCCL in the timed region)'
+                            .format(batch * world, world) if world > 1 else
+                            ' (north_star target; BASELINE configs[1] = batch 1024 under '
+                            '"secondary")',
+                            args.steps, args.scheme, dt),
             'equation': type(eq).__name__, 'num_points': n,
             'batch_per_gpu': batch, 'global_batch': batch * world,
             'scheme': args.scheme, 'stages': stages, 'dt': dt,
@@ -532,8 +759,13 @@ def main():
         },
         'roofline': s['roofline'],
         'secondary': secondary,
+        'configs': configs,
+        'per_rank': m['per_rank'],
         'clocks': m['clocks'],
     }
+    if not m['finite']:
+      result['invalid'] = 'non-finite state after the timed run'
+
     if world == 1 and args.cpu_seconds > 0:
       result['cpu_baseline'] = cpu_baseline(model, forcing, y0_host, args.scheme,
                                             dt, args.cpu_seconds)
@@ -566,8 +798,9 @@ def measured_traffic(equation, num_points, batch, launch_mode, fixed, state_dtyp
       continue
     for entry in table.get('entries', []):
       if entry.get('match') == want:
-        return entry['traffic_bytes_per_launch'], 'profiles/' + name
-  return None, None
+        return (entry['traffic_bytes_per_launch'], 'profiles/' + name,
+                entry.get('command', table.get('command')))
+  return None, None, None
 
 
 if __name__ == '__main__':

@@ -52,7 +52,7 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
 }
 
 template <int kRows, int kWR, bool kHoist, int kEq>
-__global__ __launch_bounds__(kRows / kWR * 64, 1) void adaptive_kernel(DevParams p,
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams p,
                                                                        AdaptiveArgs a) {
   __shared__ Shared<kRows, kWR> sm;
   __shared__ double red[kRows == kWR ? 2 : kRows];
@@ -74,7 +74,12 @@ __global__ __launch_bounds__(kRows / kWR * 64, 1) void adaptive_kernel(DevParams
 
   double t = t0;
   double y = ln.valid ? a.y0[ln.gidx] : 0.0;
-  double y_new = y, h = 0.0, h_abs = 0.0, h0 = 0.0, d1 = 0.0, t_new = t0, min_step = 0.0;
+  double y_new = y, h = 0.0, h_abs = 0.0, t_new = t0;
+  // select_initial_step's h0 and d1 live only until the first attempt starts:
+  // they share the registers of h and t_new (set by begin_attempt after their
+  // last use), which keeps the loop-carried state inside the register budget
+  double& h0 = h;
+  double& d1 = t_new;
   float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f;
   int status = ln.valid ? 1 : 0;   // 1 running, 0 finished, -1 / -2 failed
   int nfev = 0, ti = 0;
@@ -82,8 +87,11 @@ __global__ __launch_bounds__(kRows / kWR * 64, 1) void adaptive_kernel(DevParams
   long long attempts = 0;
 
   // RungeKutta._step_impl, head: limits of the step about to be attempted
+  const auto min_step_at = [](double tc) {
+    return 10.0 * fabs(nextafter(tc, (double)INFINITY) - tc);
+  };
   const auto begin_step = [&]() {
-    min_step = 10.0 * fabs(nextafter(t, (double)INFINITY) - t);
+    const double min_step = min_step_at(t);
     if (h_abs > max_step) h_abs = max_step;
     else if (h_abs < min_step) h_abs = min_step;
     rejected = false;
@@ -91,7 +99,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 1) void adaptive_kernel(DevParams
   // ... and the head of its attempt loop
   const auto begin_attempt = [&]() {
     if (status != 1) return;
-    if (h_abs < min_step || !(h_abs == h_abs)) {   // TOO_SMALL_STEP (a NaN step would spin forever)
+    if (h_abs < min_step_at(t) || !(h_abs == h_abs)) {   // TOO_SMALL_STEP (a NaN step would spin forever)
       status = -1;
       return;
     }

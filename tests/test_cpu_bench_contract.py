@@ -22,13 +22,13 @@ def test_measured_traffic_lookup():
   assert newest['entries'], 'PMC table is empty'
   # the default run (north_star target: batch 4096) and configs[1] are profiled
   for batch in (4096, 1024):
-    got, source = bench.measured_traffic('ConservativeBurgersEquation', 64, batch,
-                                         'persistent', False)
+    got, source, _ = bench.measured_traffic('ConservativeBurgersEquation', 64, batch,
+                                            'persistent', False)
     assert got and source == 'profiles/' + bench.TRAFFIC_TABLES[0]
   for entry in newest['entries']:
     m = entry['match']
-    got, source = bench.measured_traffic(m['equation'], m['num_points'], m['batch_per_gpu'],
-                                         m['launch_mode'], m['fixed'])
+    got, source, _ = bench.measured_traffic(m['equation'], m['num_points'],
+                                            m['batch_per_gpu'], m['launch_mode'], m['fixed'])
     assert got == entry['traffic_bytes_per_launch'] and source.startswith('profiles/')
     # FETCH_SIZE (with the gfx950 correction) + WRITE_SIZE, in bytes
     want = 1024 * (entry['fetch_correction'] * entry['fetch_size_kb'] + entry['write_size_kb'])
@@ -36,7 +36,7 @@ def test_measured_traffic_lookup():
   # the headline configuration is in the table; unprofiled ones report null
   assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1024, 'persistent', False)[0]
   assert bench.measured_traffic('ConservativeBurgersEquation', 64, 1000, 'persistent',
-                                False) == (None, None)
+                                False) == (None, None, None)
 
 
 def test_bench_defaults_match_baseline_config():
@@ -47,6 +47,14 @@ def test_bench_defaults_match_baseline_config():
   assert (args.gpus, args.steps, args.batch, args.num_points, args.equation) == (
       1, 1000, 4096, 64, 'burgers')
   assert args.secondary_batch == 1024
-  assert args.preheat_ms >= 200.0 and args.min_timed_ms >= 20.0
+  # a timed region the driver's GPU-activity sampler can see
+  assert args.preheat_ms >= 200.0 and args.min_timed_ms >= 1000.0
+  # the rest of the contract rides in the same run at N = 1
+  assert args.configs == 'all' and set(bench.CONFIG_NAMES) >= {
+      'kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'stream_fixed',
+      'differentiator_b1', 'adaptive_rk23'}
+  # BASELINE configs[4]: 65 536 samples over 8 GPUs = 8 192 per GPU
+  assert bench.parse_args(['--gpus', '8']).batch == 8192
+  assert bench.parse_args(['--gpus', '8', '--batch', '512']).batch == 512
   assert args.scheme == 'midpoint' and args.launch_mode == 'persistent'
   assert bench.PEAK_FP32_TFLOPS == 157.3 and bench.PEAK_HBM_GBPS == 8000.0

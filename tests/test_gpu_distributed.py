@@ -98,6 +98,11 @@ def test_bench_two_ranks_on_this_box():
   assert result['config']['backend'] == 'gloo' and result['config']['finite']
   assert result['steps'] == 20 and result['reps'] >= 1 and result['value'] > 0
   assert result['cpu_baseline'] is None and result['secondary'] is None
+  # every rank's own times and the isolated gather cost ride in the line
+  per_rank = result['per_rank']
+  assert len(per_rank['kernel_ms']) == 2 and len(per_rank['wall_ms']) == 2
+  assert len(per_rank['gather_ms_isolated']) == 2 and per_rank['gather_bytes_per_rank'] == 512 * 64 * 4
+  assert result['configs'] is None
 
 
 def test_bench_rccl_path_with_one_rank():
