@@ -119,8 +119,9 @@ def parse_args(argv=None):
                        'memory and lets several ranks share one GPU (tests of the N > 1 '
                        'code path on a one-GPU box; never a headline number)')
   ap.add_argument('--debug-option', action='append', default=[], metavar='NAME=VALUE',
-                  help='library A/B switch (ddd_debug_set_option), e.g. no_spec=1; '
-                       'logged to stderr, never set in a headline run')
+                  help='library A/B switch (ddd_debug_set_option of libddd1d_probe.so, '
+                       '__graft_entry__.build_probe), e.g. no_spec=1; logged to stderr, never '
+                       'set in a headline run')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
   args = ap.parse_args(argv)
@@ -684,7 +685,11 @@ def main():
       dist.init_process_group('gloo')
 
   import ddd1d_amd
-  lib = ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
+  if args.debug_option:
+    # A/B switches live in the probe flavour of the library only (never a headline run)
+    lib = ddd1d_amd._lib.load_probe_library()
+  else:
+    lib = ddd1d_amd._lib.load_library()   # raises if the HIP extension is missing
   for item in args.debug_option:
     name, _, value = item.partition('=')
     ddd1d_amd._lib.debug_set_option(name, int(value or '1'))

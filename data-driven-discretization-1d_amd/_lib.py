@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(_HERE, 'csrc', 'libddd1d.so')
+PROBE_LIBRARY_PATH = os.path.join(_HERE, 'csrc', 'libddd1d_probe.so')
 
 MAX_DERIVATIVES = 4
 
@@ -306,10 +307,25 @@ def apply_space_derivatives(equation_id: int, derivatives, inputs, eta: float, d
   return out
 
 
+def load_probe_library():
+  """dlopen libddd1d_probe.so (the -DDDD_PROBES flavour: ddd_debug_* entry points,
+  phase tracing, hardware probes) INSTEAD of the product library.  Only
+  profiles/tools/ and `bench.py --debug-option` do this, before any other call."""
+  if not os.path.exists(PROBE_LIBRARY_PATH):
+    raise ImportError(
+        '{} not found: build it with `python -c "import __graft_entry__ as g; '
+        'g.build_probe()"`'.format(PROBE_LIBRARY_PATH))
+  return load_library(PROBE_LIBRARY_PATH)
+
+
 def debug_set_option(name: str, value: int):
-  """Profiling / A-B switches of the library (capi.hip: ddd_debug_set_option);
-  every change is logged to stderr by the library.  Not a product API."""
+  """Profiling / A-B switches (capi.hip: ddd_debug_set_option); every change is
+  logged to stderr by the library.  They exist in libddd1d_probe.so only: the
+  product library has no such entry point (load_probe_library first)."""
   lib = load_library()
+  if not hasattr(lib, 'ddd_debug_set_option'):
+    raise DDDError('the product library has no debug switches: call '
+                   '_lib.load_probe_library() (libddd1d_probe.so) before anything else')
   fn = lib.ddd_debug_set_option
   fn.restype = ctypes.c_int
   fn.argtypes = [ctypes.c_char_p, ctypes.c_longlong]

@@ -17,6 +17,9 @@
 #include "dev_params.h"
 #include "launch.h"
 #include "ops.h"
+#ifdef DDD_PROBES
+#include "probe_kernels.h"
+#endif
 #include "rhs_generic.h"
 #include "rhs_mfma.h"
 #include "rhs_spectral.h"
@@ -26,10 +29,13 @@ namespace {
 
 thread_local std::string g_error;
 
-// Profiling / A-B switches.  They are set ONLY through ddd_debug_set_option
-// (an explicit call that logs to stderr), never read from the environment: a
-// stray variable must not be able to change the numerics path, skip kernel
-// phases or hand the kernel a raw address.
+// Profiling / A-B switches.  The product library (libddd1d.so) has none: the
+// struct below is constant there and every test on it folds away.  In
+// libddd1d_probe.so (-DDDD_PROBES, __graft_entry__.build_probe, used only by
+// profiles/tools/ and `bench.py --debug-option`) they are set ONLY through
+// ddd_debug_set_option (an explicit call that logs to stderr), never read from
+// the environment: a stray variable must not be able to change the numerics
+// path, skip kernel phases or hand the kernel a raw address.
 struct DebugOptions {
   int no_fold = 0;       // keep the projection out of the output layer (D <= 2 models)
   int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
@@ -39,7 +45,11 @@ struct DebugOptions {
   int ablate = 0;        // skips kernel phases: WRONG RESULTS (run-time-parameterised kernels)
   unsigned long long trace_ptr = 0;   // device buffer for s_memtime phase stamps
 };
+#ifdef DDD_PROBES
 DebugOptions g_debug;
+#else
+constexpr DebugOptions g_debug{};
+#endif
 
 int fail(int code, const char* fmt, ...) {
   char buf[1024];
@@ -154,7 +164,6 @@ struct ddd_model {
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
   bool spec_folded = false;          // w_final4 (specialised kernels) holds the folded output layer
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
-  const char* last_substep_kernel = "";   // kernel of the most recent fused-substep launch
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
@@ -209,6 +218,27 @@ int common_config_checks(const ddd_config* cfg) {
   return DDD_OK;
 }
 
+// rhs_mfma.h replaces u / stddev by q' = fma(fma(-q, s, u), r, q), q = RN(u r),
+// r = RN(1 / s).  True for every float32 u iff it is true for the 2^23
+// significands of one binade (scaling u by a power of two scales q, the
+// residual and q' exactly, away from under/overflow).  ~0.1 s, cached per value.
+bool division_shortcut_is_exact(float s) {
+  static std::vector<std::pair<float, bool>> cache;
+  for (const auto& kv : cache)
+    if (std::memcmp(&kv.first, &s, sizeof(s)) == 0) return kv.second;
+  const float r = (float)(1.0 / (double)s);
+  bool exact = std::isfinite(r) && r != 0.0f;
+  for (uint32_t bits = 0x3f800000u; exact && bits < 0x40000000u; ++bits) {
+    float u;
+    std::memcpy(&u, &bits, sizeof(u));
+    const float q = u * r;
+    const float fast = std::fmaf(std::fmaf(-q, s, u), r, q);
+    exact = fast == u / s;
+  }
+  cache.emplace_back(s, exact);
+  return exact;
+}
+
 void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
   std::memset(dp, 0, sizeof(*dp));
   dp->equation = cfg.equation;
@@ -218,6 +248,7 @@ void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
   dp->eta = (float)cfg.eta;
   dp->stddev = (float)cfg.standard_deviation;
   dp->inv_stddev = (float)(1.0 / (double)dp->stddev);
+  dp->exact_div = division_shortcut_is_exact(dp->stddev) ? 0 : 1;
   dp->inv_dx = (float)(1.0 / cfg.dx);
   dp->conservative = is_conservative(cfg.equation) ? 1 : 0;
 }
@@ -538,13 +569,11 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
     const unsigned blocks = (unsigned)((total + pts - 1) / pts);
     hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel, dim3(blocks),
                        dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
-    m->last_substep_kernel = "stream_fixed";
     m->last_launch_streamed = true;
     DDD_HIP(hipGetLastError());
     return DDD_OK;
   }
   m->last_launch_streamed = false;
-  m->last_substep_kernel = m->kernel == DDD_KERNEL_MFMA ? "mfma" : "generic";
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
@@ -594,12 +623,14 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   // integrate.py:154 -- in the one-wave geometry (launch.h)
   int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m, kRows) : -1;
   bool traced = false;
+#ifdef DDD_PROBES
   if (a.trace != nullptr) {
     // phase tracing: the dedicated traced instantiation (headline config) or
     // the run-time-parameterised kernel
     traced = eq == ddd::EQ_BURGERS_CONS && kRows == 64 && !f64;
     if (!traced) eq = -1;
   }
+#endif
 #define DDD_SPEC_CASE(EQ) \
   case EQ: ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); return;
   switch (eq) {
@@ -620,11 +651,12 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
   m->last_batch = a.batch;
   m->last_launch_streamed = false;
-  // profiling knobs (ddd_debug_set_option; see profiles/r1_ablation.txt); all off by default
+#ifdef DDD_PROBES   // profiling knobs (ddd_debug_set_option; profiles/r1_ablation.txt)
   a.prio_split = g_debug.prio_split;
   a.stagger = g_debug.stagger;
   a.trace = reinterpret_cast<unsigned long long*>(g_debug.trace_ptr);
   a.ablate = g_debug.ablate;
+#endif
   if (m->kernel == DDD_KERNEL_MFMA) {
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
@@ -804,6 +836,7 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
   }
   m->dp.stddev = 1.0f;
   m->dp.inv_stddev = 1.0f;
+  m->dp.exact_div = 0;
   m->fma_per_point = (int64_t)cfg->num_derivatives * cfg->stencil_size;
   std::vector<float> sv(stencils, stencils + n_stencils);
   rc = upload(sv, &m->d_bias);
@@ -1382,12 +1415,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }
 
-// Name of the kernel the most recent fused-substep launch of this model used
-// ("stream_fixed", "mfma", "generic"; "" before the first launch).  Tests only.
-const char* ddd_debug_last_substep_kernel(const ddd_model* m) {
-  return m != nullptr ? m->last_substep_kernel : "";
-}
-
+#ifdef DDD_PROBES
 // Profiling / A-B switches (not part of the product API; every change is
 // logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
 // no_stream, prio_split, stagger, ablate, trace_ptr.
@@ -1490,6 +1518,7 @@ int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* tic
   *wall_ns_per_mfma = (double)ms * 1e6 / ((double)iters * per_iter);
   return DDD_OK;
 }
+#endif  // DDD_PROBES
 
 int ddd_selftest_mfma_layout(void) {
   float* d32 = nullptr;
@@ -1548,8 +1577,5 @@ int ddd_selftest_mfma_layout(void) {
   (void)dpp_wave_rol_ok();
   return DDD_OK;
 }
-
-// 1 if the DPP wavefront rotate is usable on this device (tests / diagnostics).
-int ddd_debug_dpp_wave_rol(void) { return dpp_wave_rol_ok(); }
 
 }  // extern "C"

@@ -28,6 +28,8 @@ struct DevParams {
   int equation, N, D, G;
   float eta, stddev, inv_dx;
   float inv_stddev;    // RN(1 / stddev): seed of the three-instruction division in rhs_mfma.h
+  int exact_div;       // 1: that shortcut is NOT bit-equal to u / stddev for this stddev
+                       // (checked exhaustively on the host at model creation): divide
   int conservative;    // flux form: needs the staggered difference
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
@@ -84,10 +86,12 @@ struct IntegrateArgs {
   const void* y0;   // [batch][N] StateT
   void* y_out;      // [n_saved][batch][N] StateT
   int batch;
+#ifdef DDD_PROBES   // libddd1d_probe.so only (profiles/tools): never in the product library
   int prio_split;   // 1: odd hardware wave slots run at raised priority
-  int ablate;       // profiling only (debug option "ablate"): bit mask of phases to skip
-  int stagger;      // profiling only (debug option "stagger"): initial s_sleep count for odd waves
-  unsigned long long* trace;   // profiling only: [blocks][kTraceSlots] s_memtime stamps
+  int ablate;       // debug option "ablate": bit mask of phases to skip (WRONG results)
+  int stagger;      // debug option "stagger": initial s_sleep count for odd waves
+  unsigned long long* trace;   // [blocks][kTraceSlots] s_memtime stamps
+#endif
 };
 
 // ddd_integrate_adaptive_f64 (rhs_adaptive.h)

@@ -23,7 +23,7 @@ void integrate_spec<DDD_EQ>(int rows, bool f64, bool traced, const DevParams& p,
                          0, stream, p, a);
       return;
     }
-#if DDD_EQ == 1   // EQ_BURGERS_CONS: the headline configuration carries the phase stamps
+#if DDD_EQ == 1 && defined(DDD_PROBES)   // probe build: the headline configuration carries phase stamps
     if (traced) {
       hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ, true>), grid,
                          dim3(64), 0, stream, p, a);

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
       res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, tev[frc_sl], tid);
     }
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false>(
-        p, sm, a.batch, (float)yy, (float)tt, (float)tt, res, fast_frc, nullptr, nullptr, 64);
+        p, sm, a.batch, (float)yy, (float)tt, (float)tt, res, fast_frc, nullptr, nullptr, false);
     if (status == 1) ++nfev;
 
     if (phase == 0) {

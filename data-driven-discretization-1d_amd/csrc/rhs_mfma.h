@@ -580,13 +580,17 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 //   Equation.equation_of_motion equations.py       (dev_params.h)
 //   finalize_time_derivative    equations.py:276-277 (forcing)
 // kHoist: res.hid already holds the (single) hidden layer's weights.
+// prepare_next: also compute the harmonic forcing sums of time t_next (the
+// evaluation after this one) at the layer boundaries.
+// ablate / trace: profiling hooks of libddd1d_probe.so (-DDDD_PROBES); every
+// product call site passes the defaults, so they fold away.
 template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
-                                          float* coeffs_out, int ablate = 0,
-                                          unsigned long long* trace = nullptr,
-                                          int group = -1) {
+                                          float* coeffs_out, bool prepare_next = true,
+                                          int group = -1, int ablate = 0,
+                                          unsigned long long* trace = nullptr) {
 #define DDD_STAMP(i) do { if (kTrace && trace != nullptr && (int)threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
@@ -633,15 +637,20 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
         tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, hid_rows[t2]);
     }
   }
-  // model.py:450-451: net = u / std.  Three FMAs-class instructions instead of
+  // model.py:450-451: net = u / std.  Three FMA-class instructions instead of
   // the 12 of the IEEE division sequence: q = RN(u r), r = RN(1 / std), then one
-  // Newton step on the residual, q' = fma(fma(-q, std, u), r, q) -- the
-  // correctly rounded quotient (bit-equal to the division on 2M random inputs per
-  // standard deviation, tests/test_cpu_mfma_emulation.py); NaN propagates, an
-  // overflowing quotient (a diverged state) becomes NaN instead of Inf; every
-  // VALU instruction here is matrix-pipe time.
+  // Newton step on the residual, q' = fma(fma(-q, std, u), r, q).  Whether q' is
+  // the correctly rounded quotient for EVERY float32 u depends on std: the host
+  // checks all 2^23 significands of one binade (the identity is invariant under
+  // scaling u by powers of two) for the model's own standard deviation when the
+  // model is created (capi.hip: division_shortcut_is_exact) and sets
+  // DevParams::exact_div when a single case differs -- then the true division
+  // runs.  Outside the normal range: NaN propagates; a quotient that overflows
+  // (a diverged state) becomes NaN instead of Inf, a subnormal quotient may
+  // differ in its last bit.  Every VALU instruction here is matrix-pipe time.
   const float q_un = u * p.inv_stddev;
-  const float un_reg = fmaf(fmaf(-q_un, p.stddev, u), p.inv_stddev, q_un);
+  float un_reg = fmaf(fmaf(-q_un, p.stddev, u), p.inv_stddev, q_un);
+  if (p.exact_div) un_reg = u / p.stddev;   // wave-uniform
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
   if (!fixed && !kOneWave && ln.owner) sm.un[ln.row] = un_reg;
   // harmonic forcing sums of THIS evaluation's time: computed during the
@@ -675,7 +684,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
     if (!(ablate & 16))
       input_layer<kWR, kOneWave, kKeepRows>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act,
                                             res.in_perm);
-    const bool frc_next = forced && fast_forcing && !(ablate & 65);
+    const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     float* in = sm.hA;
     float* out = sm.hB;
@@ -729,7 +738,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
         for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
     }
   } else {
-    if (forced && fast_forcing && !(ablate & 65))
+    if (forced && fast_forcing && prepare_next && !(ablate & 1))
       res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
     __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
   }
@@ -1085,7 +1094,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
   const float f = eval_rhs<kRows, kWR, false, kEq, false>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
-                                              fast_frc, a.derivs_out, a.coeffs_out, 64);
+                                              fast_frc, a.derivs_out, a.coeffs_out, false);
   if (!ln.active) return;
   if (a.y_out != nullptr) {
     const float cf = a.c1 * f;
@@ -1140,10 +1149,10 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
                              ? a.acc_in[ln.gidx] : 0.0f;
     // `more`: the evaluation also prepares the sums of the next group (same time,
     // other samples) at its layer boundaries, as the persistent integrator does
-    // for its next stage; the last group skips that (mask 64)
+    // for its next stage; the last group has no successor
     const float f = eval_rhs<kRows, kWR, true, kEq, false>(p, sm, a.batch, u, (float)a.t,
                                                            (float)a.t, res, fast_frc, nullptr,
-                                                           nullptr, more ? 0 : 64, nullptr, grp);
+                                                           nullptr, more, grp);
     if (ln.active) {
       // (x + c f with x = 0 when there is no base array: the same bits as c f)
       if (a.y_out != nullptr) a.y_out[ln.gidx] = base + a.c1 * f;
@@ -1162,29 +1171,36 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
 // each lane keeps its grid point's state in registers, HBM sees y0 once and the
 // requested snapshots.
 // ---------------------------------------------------------------------------
-// kTrace: s_memtime phase stamps (debug option "trace_ptr", profiles/tools/trace_phases.py)
-// are compiled into the run-time-parameterised instantiation and into one
-// dedicated specialised instantiation only: their branches cost ~2 % otherwise.
-template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1, bool kTrace = (kEq < 0)>
+// kTrace (libddd1d_probe.so only): s_memtime phase stamps (debug option
+// "trace_ptr", profiles/tools/trace_phases.py), compiled into the
+// run-time-parameterised instantiation and into one dedicated specialised
+// instantiation: their branches cost ~2 % otherwise.
+#ifdef DDD_PROBES
+constexpr bool kTraceByDefault = true;
+#else
+constexpr bool kTraceByDefault = false;
+#endif
+template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1,
+          bool kTrace = (kEq < 0) && kTraceByDefault>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
                                                                         IntegrateArgs a) {
   __shared__ Shared<kRows, kWR> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
-  // Two wavefronts share each SIMD and run the same phases; left alone they
-  // phase-lock (both in their MFMA phase, then both in their VALU phase, the
-  // matrix pipe idling).  A static priority split by hardware wave slot lets
-  // one of them win every arbitration, which de-synchronises the pair so one
-  // wave's VALU / LDS phases overlap the other's MFMA phases
-  // (MI355X_MICROARCH.md "Two waves per SIMD", item 4).
-  // the ablate mask (profiling: ddd_debug_set_option("ablate")) is honoured by the run-time-parameterised
-  // instantiation only (DDD_NO_SPEC=1 selects it for the default models)
-  int ablate = kEq >= 0 ? 0 : (a.ablate & 0xff);
+  // (Two wavefronts share each SIMD and run the same phases.  Static priorities
+  // by hardware wave slot and start staggering were measured and change nothing
+  // (profiles/r2_ablation.txt); the switches survive in the probe build only.)
+  int ablate = 0;
+  unsigned long long* trace_base = nullptr;
+#ifdef DDD_PROBES
+  // the ablate mask (debug option "ablate") is honoured by the run-time-parameterised
+  // instantiation only (debug option "no_spec" selects it for the default models)
+  ablate = kEq >= 0 ? 0 : (a.ablate & 0xff);
   if (kEq < 0 && (a.ablate >> 8) != 0 &&
       ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) != 0))
     ablate = (a.ablate >> 8) & 0xff;   // high byte: mask for odd wave slots
-  if (a.prio_split) {   // A/B experiments (debug options "prio_split" / "stagger"), off by default
+  if (a.prio_split) {   // A/B experiments (debug options "prio_split" / "stagger")
     const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 0xfu;   // HW_ID.wave_id
     const bool odd = (a.prio_split & 2) ? ((blockIdx.x >> 10) & 1u) != 0 : (wave_slot & 1u) != 0;
     if (odd) {
@@ -1192,6 +1208,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
   }
+  trace_base = a.trace;
+#endif
   // traced instantiation: shader-clock ticks (s_memtime) against the constant
   // 100 MHz counter (s_memrealtime) over the whole launch -> effective clock
   const unsigned long long clk0 = kTrace ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -1215,8 +1233,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       ST us = y;
       if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
       unsigned long long* tr = nullptr;
-      if (kTrace && a.trace != nullptr && evals * 5 + 5 <= kTraceSlots)
-        tr = a.trace + (size_t)(int)blockIdx.x * kTraceSlots + evals * 5;
+      if (kTrace && trace_base != nullptr && evals * 5 + 5 <= kTraceSlots)
+        tr = trace_base + (size_t)(int)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
       // next step): its forcing sums are prepared inside this evaluation
@@ -1225,7 +1243,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
                             : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
       const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(
           p, sm, a.batch, (float)us, (float)(t + a.tab.c[s] * a.dt), (float)tn, res, fast_frc,
-          nullptr, nullptr, ablate, tr);
+          nullptr, nullptr, true, -1, ablate, tr);
       if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
       kprev = f;
     }
@@ -1236,8 +1254,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParam
       ++snap;
     }
   }
-  if (kTrace && a.trace != nullptr && threadIdx.x == 0) {
-    unsigned long long* tr = a.trace + (size_t)blockIdx.x * kTraceSlots;
+  if (kTrace && trace_base != nullptr && threadIdx.x == 0) {
+    unsigned long long* tr = trace_base + (size_t)blockIdx.x * kTraceSlots;
     tr[kTraceSlots - 2] = __builtin_amdgcn_s_memtime() - clk0;
     tr[kTraceSlots - 1] = __builtin_amdgcn_s_memrealtime() - real0;
   }

@@ -803,9 +803,17 @@ def predict_space_derivatives(inputs, model: LearnedStencilModel):
   return model.space_derivatives(inputs)
 
 
+def _forcing_changes_rhs(model) -> bool:
+  """A forcing table only enters the device right-hand side for the equations
+  whose finalize_time_derivative adds forcing(t) (the Burgers family,
+  equations.py:276-277; capi.hip: is_forced_family).  KdV / KS models may carry
+  one -- ddd_set_forcing is a documented no-op for them."""
+  return model._forcing is not None and model.equation.has_time_dependent_forcing
+
+
 def predict_time_derivative(inputs, model: LearnedStencilModel):
   """model.py:618-640: equation of motion only, no finalize (no forcing)."""
-  if model._forcing is not None:
+  if _forcing_changes_rhs(model):
     raise ValueError('predict_time_derivative excludes forcing; call '
                      'model.time_derivative(y, t) for the finalized value')
   return model.time_derivative(inputs, 0.0)
@@ -838,7 +846,7 @@ def predict_time_evolution(inputs, model: LearnedStencilModel):
   ``integrate_ode(model, ...)`` / ``model.integrate_fixed`` for the forced
   trajectory.
   """
-  if model._forcing is not None:
+  if _forcing_changes_rhs(model):
     raise ValueError('predict_time_evolution excludes forcing (model.py:655-657); '
                      'call model.set_forcing(None) first, or use integrate_ode / '
                      'model.integrate_fixed for the forced trajectory')

@@ -2,7 +2,7 @@ import ctypes, os, sys, numpy as np, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ddd1d_amd
-lib = ddd1d_amd._lib.load_library()
+lib = ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
 torch.zeros(1).cuda()
 blocks = 2048
 out = np.zeros((blocks, 4), dtype=np.uint32)

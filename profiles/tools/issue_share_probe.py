@@ -2,7 +2,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ddd1d_amd
-lib = ddd1d_amd._lib.load_library()
+lib = ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
 torch.zeros(1).cuda()
 fn = lib.ddd_debug_issue_share
 fn.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_double)] * 2

@@ -1,7 +1,7 @@
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, ddd1d_amd
-lib = ddd1d_amd._lib.load_library()
+lib = ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
 torch.zeros(1).cuda()
 lib.ddd_debug_mfma_rate.argtypes = [ctypes.c_int]*4 + [ctypes.POINTER(ctypes.c_double)]*2
 NAMES = {1: '32x32x2', 0: '16x16x4', 2: '4x4x1_16b(cbsz4)'}

@@ -2,6 +2,7 @@ import os, sys, json, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ddd1d_amd
 from ddd1d_amd import equations, model as model_lib
+ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}))
 _, eq = equations.from_hparams(hp)

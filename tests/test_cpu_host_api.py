@@ -32,7 +32,12 @@ def test_library_exports_every_declared_symbol():
   out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIBRARY_PATH],
                        capture_output=True, text=True, check=True).stdout
   exported = set(re.findall(r' T (ddd_[a-z0-9_]+)', out))
-  assert set(declared) <= exported
+  # product ABI == the header: no profiling / debug entry points ride along
+  # (those live in libddd1d_probe.so, __graft_entry__.build_probe)
+  assert exported == set(declared), sorted(exported ^ set(declared))
+  assert not hasattr(lib, 'ddd_debug_set_option')
+  with pytest.raises(_lib.DDDError, match='probe'):
+    _lib.debug_set_option('no_spec', 1)
   assert lib.ddd_abi_version() == 1
   assert [lib.ddd_scheme_stages(s) for s in range(4)] == [1, 2, 3, 4]
   assert lib.ddd_scheme_stages(9) == -1

@@ -209,8 +209,18 @@ def test_integrate_baseline_vs_reference_golden(golden, cls_name, n, rf, seed, a
   got = np.asarray(ds['y'])
   assert got.shape == want.shape
   # the reference evaluates the RHS in float32 inside TF; the golden RHS is
-  # float64, so allow the float32 RHS noise on top of 1e-5
-  assert rel_err(got, want) < 5e-5
+  # float64.  Bound: 1e-5, or 4 x the distance of the float32 NumPy restatement
+  # (same SciPy run) from the golden trajectory where that float32 noise is larger
+  from helpers import baseline_spec
+  spec = baseline_spec(eq, acc)
+  frc = ({k: v[0] for k, v in model_lib.forcing_from_equations([eq]).items()}
+         if eq.has_time_dependent_forcing else None)
+  f32_run, _ = oracle.odeint_rk23(spec, eq.initial_value(), times, frc)
+  floor = rel_err(f32_run, want)
+  err = rel_err(got, want)
+  print(key, 'HIP vs reference {:.1e}; float32 restatement vs reference {:.1e}'
+        .format(err, floor))
+  assert err < max(TOL, 4 * floor)
   assert int(ds.coords['num_evals']) == int(golden[key + '/nfev'])
   # single RHS evaluation as well
   diff = integrate.PolynomialDifferentiator(eq, acc)
@@ -221,8 +231,11 @@ def test_integrate_baseline_vs_reference_golden(golden, cls_name, n, rf, seed, a
 
 
 def test_integrate_batch_matches_per_sample_scipy():
-  """Batched fixed-step BS3 at dt = max_step reproduces the adaptive RK23 runs
-  of the reference while its controller sits at max_step (smooth Burgers)."""
+  """integrate_batch(adaptive=True) = the reference's per-sample RK23 runs (equal
+  nfev, 1e-5).  The fixed-step BS3 form at dt = max_step is a DIFFERENT step
+  sequence (no small first steps): close while the controller sits at max_step
+  (smooth Burgers), asserted at 2e-4 as a statement about the two algorithms,
+  not as a parity tolerance."""
   hp_model = make_model('burgers', True, num_points=32, resample_factor=16)
   batch = 3
   times = np.linspace(0, 0.2, 3)
@@ -232,10 +245,14 @@ def test_integrate_batch_matches_per_sample_scipy():
                                  forcing=forcing, state_dtype='float64')
   y = np.asarray(ds['y'])
   assert y.shape == (batch, 3, 32)
+  ada = integrate.integrate_batch(hp_model, y0, times, dt=0.01, forcing=forcing,
+                                  adaptive=True)
+  y_ada = np.asarray(ada['y'])
+  nfev = np.asarray(integrate._dataset_coord(ada, 'num_evals'))
   for b in range(batch):
     one = {k: v[b] for k, v in forcing.items()}
-    want, _ = oracle.odeint_rk23(hp_model.spec(), y0[b], times, one)
-    # adaptive vs fixed stepping differ in the first (small) steps: 1e-4
+    want, want_nfev = oracle.odeint_rk23(hp_model.spec(), y0[b], times, one)
+    assert nfev[b] == want_nfev and rel_err(y_ada[b], want) < TOL
     assert rel_err(y[b], want) < 2e-4
 
 

@@ -15,9 +15,12 @@ from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-5          # Burgers / KdV: north_star's float32 tolerance
-TOL_KS = 2e-4       # KS: 4th derivative stencils (|c| ~ 6/dx^4) on smooth data
-                    # cancel ~1e4-fold; see test_f32_noise_floor_ks
+TOL = 1e-5          # north_star's float32 tolerance
+# KS: 4th-derivative stencils (|c| ~ 6/dx^4) on smooth data cancel ~1e4-fold, so
+# two float32 evaluations of the same formulas differ by more than 1e-5 whatever
+# the hardware.  No fixed relaxation: every KS assertion is bounded by 4 x the
+# MEASURED distance between the float32 oracle and a float64 evaluation of the
+# same formulas on the same inputs (_measured_tol, printed).
 
 ALL_EQUATIONS = [
     ('burgers', False, False), ('burgers', True, False), ('burgers', True, True),
@@ -26,23 +29,49 @@ ALL_EQUATIONS = [
 ]
 
 
-def _tol(equation):
-  return TOL_KS if equation == 'ks' else TOL
+def _f64_derivatives(spec, y0):
+  """Stencil apply in float64 from the float32 coefficients; None for heads
+  that do not predict coefficients."""
+  if spec.get('model_target', 'coefficients') != 'coefficients':
+    return None
+  coeff = oracle.predict_coefficients(y0, spec).astype(np.float64)
+  patches = oracle.extract_patches(y0.astype(np.float64), coeff.shape[3])
+  return np.einsum('bxdi,bxi->bxd', coeff, patches)
 
 
-def _check_all_views(model, y0, t, forcing, tol):
+def _measured_tol(spec, y0, t, forcing, want):
+  """max(1e-5, 4 x float32 noise floor of the oracle itself on these inputs)."""
+  truth = _f64_truth(spec, y0)
+  if spec.get('forced', False) and forcing is not None:
+    truth = truth + oracle.forcing_f64(t, forcing, spec['num_points'],
+                                       spec['resample_factor'], spec['period'],
+                                       spec['conservative'])
+  floor = rel_err(want, truth)
+  return max(TOL, 4 * floor), floor
+
+
+def _check_all_views(model, y0, t, forcing, tol=None):
   spec = model.spec()
   got = model.time_derivative(y0, t).cpu().numpy()
   want = oracle.time_derivative(spec, t, y0, forcing)
   err = rel_err(got, want)
+  if tol is None:
+    tol, floor = _measured_tol(spec, y0, t, forcing, want)
+    if tol > TOL:
+      print('float32 noise floor of the oracle {:.1e} -> bound {:.1e}; measured {:.1e}'
+            .format(floor, tol, err))
   assert np.isfinite(got).all()
   assert err < tol, ('time_derivative', model.kernel_name, err)
   if spec.get('model_target', 'coefficients') in ('coefficients', 'space_derivatives'):
     d_got = model.space_derivatives(y0).cpu().numpy()
     d_want = oracle.predict_space_derivatives(y0, spec)
+    d_truth = _f64_derivatives(spec, y0)
     for d in range(d_want.shape[-1]):
       e = rel_err(d_got[..., d], d_want[..., d])
-      assert e < 10 * tol, ('space_derivatives', d, model.kernel_name, e)
+      # per derivative: 1e-5, or 4 x the float32 oracle's own noise on THIS derivative
+      # (a single high-order derivative cancels more than their combination u_t)
+      bound = TOL if d_truth is None else max(TOL, 4 * rel_err(d_want[..., d], d_truth[..., d]))
+      assert e < bound, ('space_derivatives', d, model.kernel_name, e, bound)
   if spec.get('model_target', 'coefficients') == 'coefficients':
     c_got = model.coefficients(y0).cpu().numpy()
     c_want = oracle.predict_coefficients(y0, spec)
@@ -63,7 +92,7 @@ def test_time_derivative_all_equations(equation, conservative, numerical_flux,
   y0 = random_phase_ic(model.equation, batch)
   forcing = batch_forcing(batch, seed0=50)
   model.set_forcing(forcing)
-  err = _check_all_views(model, y0, 0.37, forcing, _tol(equation))
+  err = _check_all_views(model, y0, 0.37, forcing, None if equation == 'ks' else TOL)
   print('{} cons={} flux={} {}: rel err {:.2e}'.format(
       equation, conservative, numerical_flux, kernel, err))
 
@@ -304,3 +333,23 @@ def test_rows_per_workgroup_selection():
   # same arithmetic, different tiling
   np.testing.assert_array_equal(results['mfma64'], results['mfma64w32'])
   np.testing.assert_array_equal(results['mfma64'], results['mfma256'])
+
+
+def test_standard_deviation_without_exact_division_shortcut():
+  """rhs_mfma.h scales the input with a three-instruction reciprocal + one
+  correction; ddd_model_create checks exhaustively (2^23 significands) that this
+  equals u / std bit for bit for the model's standard deviation and falls back
+  to the true division otherwise.  float32(1.9999999) (all-ones significand) is
+  such a value; the reference constants 0.7917 / 0.594 / 0.299 are not."""
+  model = make_model('kdv', True, num_points=64)
+  model.equation._STANDARD_DEVIATION = float(np.float32(1.9999999))   # this instance only
+  if True:
+    spec = model.spec()
+    assert spec['standard_deviation'] == float(np.float32(1.9999999))
+    y0 = random_phase_ic(model.equation, 5)
+    got = model.time_derivative(y0, 0.0).cpu().numpy()
+    assert model.kernel_name.startswith('mfma_f32')
+    assert rel_err(got, oracle.time_derivative(spec, 0.0, y0, None)) < TOL
+    traj = model.integrate_fixed(y0, 20, dt=2.5e-5, save_every=20).cpu().numpy()
+    want = oracle.integrate_fixed(spec, oracle.SCHEME_MIDPOINT, 0.0, 2.5e-5, 20, 20, y0)
+    assert rel_err(traj, want) < TOL

@@ -1,8 +1,6 @@
 """Streaming fixed-stencil substep kernel (csrc/rhs_stream.h): the HBM-shaped
 variant of PolynomialDifferentiator / integrate_baseline
 (integrate.py:74-105, model.py:59-135) used with one launch per substep."""
-import ctypes
-
 import numpy as np
 import pytest
 
@@ -15,10 +13,9 @@ TOL = 1e-5   # float32 trajectories within 1e-5 rel of the oracle
 
 
 def last_substep_kernel(model):
-  lib = _lib.load_library()
-  lib.ddd_debug_last_substep_kernel.restype = ctypes.c_char_p
-  lib.ddd_debug_last_substep_kernel.argtypes = [ctypes.c_void_p]
-  return lib.ddd_debug_last_substep_kernel(model._handle).decode()
+  """Kernel family of the most recent launch (ddd_kernel_name)."""
+  name = model.kernel_name
+  return 'mfma' if name.startswith('mfma') else name
 
 
 def make_baseline(cls, n, rf=1, **kw):
