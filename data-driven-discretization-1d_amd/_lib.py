@@ -100,6 +100,8 @@ SIGNATURES = {
                                                   ctypes.c_double,
                                                   ctypes.c_longlong, _V, _V,
                                                   _V, _V, ctypes.c_int, _V]),
+    'ddd_circulant_apply_f64': (ctypes.c_int, [_V, _V, _V, ctypes.c_int,
+                                               ctypes.c_int, _V]),
     'ddd_time_derivative_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
                                                ctypes.c_int, _V]),
     'ddd_rk_substep_f64': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
@@ -304,6 +306,22 @@ def apply_space_derivatives(equation_id: int, derivatives, inputs, eta: float, d
   check(lib.ddd_apply_space_derivatives(int(equation_id), d.data_ptr(), x.data_ptr(),
                                         out.data_ptr(), x.shape[0], x.shape[1], d.shape[2],
                                         float(eta), float(dx), current_stream()))
+  return out
+
+
+def circulant_apply(kernel, inputs):
+  """out[..., x] = sum_j kernel[(x - j) mod n] inputs[..., j] in float64 on the
+  device (ddd_circulant_apply_f64): duckarray.smoothing_filter as a kernel."""
+  lib = load_library()
+  torch = require_gpu()
+  k = as_device(kernel, torch.float64)
+  x = as_device(inputs, torch.float64)
+  if k.dim() != 1 or x.shape[-1] != k.shape[0]:
+    raise ValueError('kernel [n] and inputs [..., n] expected')
+  out = torch.empty_like(x)
+  rows = x.numel() // k.shape[0]
+  check(lib.ddd_circulant_apply_f64(k.data_ptr(), x.data_ptr(), out.data_ptr(), rows,
+                                    k.shape[0], current_stream()))
   return out
 
 

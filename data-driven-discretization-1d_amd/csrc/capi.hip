@@ -1210,7 +1210,8 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
                                double atol, double max_step, long long max_attempts,
                                const double* y0, double* y_out, int32_t* nfev,
                                int32_t* status, int batch, void* stream_) {
-  int rc = check_batch(m, batch);
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  int rc = check_batch(m, batch, m->spectral);
   if (rc) return rc;
   if (times == nullptr || n_times < 1)
     return fail(DDD_ERR_INVALID_ARGUMENT, "times must hold at least one value");
@@ -1221,10 +1222,10 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     return fail(DDD_ERR_INVALID_ARGUMENT, "rtol and max_step must be positive, atol >= 0");
   if (batch > 0 && (!y0 || !y_out || !nfev || !status))
     return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
-  if (m->kernel != DDD_KERNEL_MFMA)
+  if (!m->spectral && m->kernel != DDD_KERNEL_MFMA)
     return fail(DDD_ERR_UNSUPPORTED,
-                "the on-device adaptive integrator runs on the MFMA kernel family only (%s)",
-                m->mfma_reason.c_str());
+                "the on-device adaptive integrator runs on the MFMA kernel family and on "
+                "spectral models only (%s)", m->mfma_reason.c_str());
   if (batch == 0) return DDD_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (m->times_capacity < (size_t)n_times) {
@@ -1249,6 +1250,26 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   a.max_attempts = max_attempts;
   m->last_batch = batch;
   m->last_launch_streamed = false;
+  if (m->spectral) {
+    // float64 right-hand side (SpectralDifferentiator), one workgroup per sample
+    const size_t lds = ddd::spectral::lds_bytes(m->sp);
+    const int pts = (m->sp.N + ddd::spectral::kThreads - 1) / ddd::spectral::kThreads;
+#define DDD_SPECTRAL_ADAPTIVE(PTS)                                                           \
+    do {                                                                                     \
+      DDD_HIP(hipFuncSetAttribute(                                                           \
+          reinterpret_cast<const void*>(ddd::spectral::adaptive_kernel<PTS>),                \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+      hipLaunchKernelGGL((ddd::spectral::adaptive_kernel<PTS>), dim3(batch),                 \
+                         dim3(ddd::spectral::kThreads), lds, stream, m->sp, a);              \
+    } while (0)
+    if (pts <= 1) DDD_SPECTRAL_ADAPTIVE(1);
+    else if (pts <= 2) DDD_SPECTRAL_ADAPTIVE(2);
+    else if (pts <= 4) DDD_SPECTRAL_ADAPTIVE(4);
+    else DDD_SPECTRAL_ADAPTIVE(8);
+#undef DDD_SPECTRAL_ADAPTIVE
+    DDD_HIP(hipGetLastError());
+    return DDD_OK;
+  }
   m->dp.dpp_rol = dpp_wave_rol_ok();
   MfmaGeometry geo = mfma_geometry(m, batch);
   if (geo.wave_rows != 64) geo = {64, 64};   // the two-wave split has no adaptive instantiation
@@ -1268,6 +1289,21 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
       if (geo.rows == 64) ddd::launch::adaptive_runtime_unit<64>(m->dp, a, blocks, stream);
       else ddd::launch::adaptive_runtime_unit<256>(m->dp, a, blocks, stream);
   }
+  DDD_HIP(hipGetLastError());
+  return DDD_OK;
+}
+
+int ddd_circulant_apply_f64(const double* kernel, const double* in, double* out, int rows,
+                            int n, void* stream) {
+  if (!kernel || !in || !out) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (rows < 0 || n < 1 || n > ddd::spectral::kMaxPoints)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "rows >= 0 and 1 <= n <= %d required",
+                ddd::spectral::kMaxPoints);
+  if (rows == 0) return DDD_OK;
+  const size_t lds = 2 * (size_t)n * sizeof(double);
+  hipLaunchKernelGGL(ddd::spectral::circulant_apply_kernel, dim3(rows),
+                     dim3(ddd::spectral::kThreads), lds, static_cast<hipStream_t>(stream),
+                     kernel, in, out, n);
   DDD_HIP(hipGetLastError());
   return DDD_OK;
 }

@@ -8,8 +8,17 @@
 // over).  One workgroup per sample; y and the D kernels sit in LDS as float64;
 // each thread owns grid points and runs D dot products of length N (N <= 2048).
 // The reference evaluates this path in float64 NumPy; so does this kernel.
+//
+// Also here, both float64 and both for the exact KdV / KS solver that produces
+// training data and evaluation baselines (integrate_exact, integrate.py:282-293):
+//   adaptive_kernel          SciPy RK23 with one controller per sample, one
+//                            workgroup per sample (rk23.h), whole solve in one launch
+//   circulant_apply_kernel   duckarray.smoothing_filter (duckarray.py:116-128): the
+//                            low-pass filter of odeint_with_periodic_filtering
+//                            (integrate.py:172-212) is a circulant operator too
 #pragma once
 #include "dev_params.h"
+#include "rk23.h"
 
 namespace ddd {
 namespace spectral {
@@ -78,6 +87,202 @@ __global__ __launch_bounds__(kThreads) void substep_kernel(Params p, SubstepArgs
       const double cf = a.c2 * f;
       a.acc_out[gi] = a.acc_in != nullptr ? a.acc_in[gi] + cf : cf;
     }
+  }
+}
+
+// Right-hand side of the workgroup's sample at the points this thread owns
+// (pos = tid + i kThreads): u = stage input in LDS (complete), c = the D kernels.
+template <int kPts>
+__device__ __forceinline__ void eval_points(const Params& p, const double* __restrict__ u,
+                                            const double* __restrict__ c, double (&f)[kPts]) {
+  const int n = p.N;
+#pragma unroll
+  for (int i = 0; i < kPts; ++i) {
+    const int pos = (int)threadIdx.x + i * kThreads;
+    f[i] = 0.0;
+    if (pos >= n) continue;
+    double dv[kMaxDerivs] = {0.0, 0.0, 0.0, 0.0};
+    int idx = pos;   // (pos - j) mod N
+    for (int j = 0; j < n; ++j) {
+      const double uj = u[j];
+#pragma unroll
+      for (int d = 0; d < kMaxDerivs; ++d)
+        if (d < p.D) dv[d] = fma(c[d * n + idx], uj, dv[d]);
+      idx = idx == 0 ? n - 1 : idx - 1;
+    }
+    f[i] = equation_rhs(p.equation, u[pos], dv, p.eta);
+  }
+}
+
+// Sum over the workgroup, identical on every thread: wave butterflies, then the
+// four wave totals in a fixed order.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double s = ((red[0] + red[1]) + red[2]) + red[3];
+  __syncthreads();
+  return s;
+}
+
+// integrate.odeint over SpectralDifferentiator (integrate.py:108-121, 143-169)
+// for a batch of samples: SciPy's RK23 (rk23.h) with float64 right-hand side,
+// one workgroup and one controller per sample, kPts grid points per thread.
+// The equations of motion are autonomous and carry no forcing here (KdV / KS:
+// finalize_time_derivative is the identity, equations.py:417-419, 528-530).
+template <int kPts>
+__global__ __launch_bounds__(kThreads) void adaptive_kernel(Params p, AdaptiveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem64[];
+  double* u = smem64;
+  double* c = smem64 + p.N;
+  __shared__ double red[4];
+  const int n = p.N;
+  const int tid = (int)threadIdx.x;
+  const size_t off = (size_t)blockIdx.x * n;
+  const size_t row_stride = (size_t)a.batch * n;
+  for (int i = tid; i < p.D * n; i += kThreads) c[i] = p.kernels[i];
+
+  const double t0 = a.times[0];
+  const double t_bound = a.times[a.n_times - 1];
+  const double interval = fabs(t_bound - t0);
+  const double rtol = a.rtol, atol = a.atol, max_step = a.max_step;
+  const double sqrt_n = sqrt((double)n);
+  double y[kPts], y_new[kPts], k0[kPts], k1[kPts], k2[kPts], f[kPts];
+#pragma unroll
+  for (int i = 0; i < kPts; ++i) {
+    const int pos = tid + i * kThreads;
+    y[i] = pos < n ? a.y0[off + pos] : 0.0;
+    y_new[i] = y[i]; k0[i] = k1[i] = k2[i] = 0.0;
+  }
+  const auto rms = [&](const double (&q)[kPts]) {
+    double part = 0.0;
+#pragma unroll
+    for (int i = 0; i < kPts; ++i)
+      if (tid + i * kThreads < n) part += q[i] * q[i];
+    return sqrt(block_sum(part, red)) / sqrt_n;
+  };
+
+  rk23::Control ctl;
+  ctl.init(t0, true);
+  double h0 = 0.0, d1 = 0.0;
+  long long attempts = 0;
+  int phase = 0;
+  while (ctl.status == rk23::RUNNING) {   // the controller is uniform over the workgroup
+#pragma unroll
+    for (int i = 0; i < kPts; ++i) {
+      const int pos = tid + i * kThreads;
+      if (pos >= n) continue;
+      double yy;
+      if (phase == 0) yy = y[i];
+      else if (phase == 1) yy = y[i] + h0 * k0[i];
+      else if (phase == 2) yy = rk23::stage2_input(y[i], k0[i], ctl.h);
+      else if (phase == 3) yy = rk23::stage3_input(y[i], k0[i], k1[i], ctl.h);
+      else yy = y_new[i];
+      u[pos] = yy;
+    }
+    __syncthreads();
+    eval_points<kPts>(p, u, c, f);
+    __syncthreads();
+    ++ctl.nfev;
+    double q[kPts];
+    if (phase == 0) {
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) k0[i] = f[i];
+      if (a.n_times == 1) {
+#pragma unroll
+        for (int i = 0; i < kPts; ++i)
+          if (tid + i * kThreads < n) a.y_out[off + tid + i * kThreads] = y[i];
+        ctl.ti = 1;
+        ctl.status = rk23::FINISHED;
+      } else {
+#pragma unroll
+        for (int i = 0; i < kPts; ++i) q[i] = y[i] / (atol + fabs(y[i]) * rtol);
+        const double d0 = rms(q);
+#pragma unroll
+        for (int i = 0; i < kPts; ++i) q[i] = k0[i] / (atol + fabs(y[i]) * rtol);
+        d1 = rms(q);
+        h0 = rk23::Control::first_guess(d0, d1, interval);
+      }
+      phase = 1;
+    } else if (phase == 1) {
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) q[i] = (f[i] - k0[i]) / (atol + fabs(y[i]) * rtol);
+      const double d2 = rms(q) / h0;
+      ctl.initial_step(h0, d1, d2, interval, max_step);
+      ctl.begin_step(max_step);
+      ctl.begin_attempt(t_bound);
+      phase = 2;
+    } else if (phase == 2) {
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) k1[i] = f[i];
+      phase = 3;
+    } else if (phase == 3) {
+#pragma unroll
+      for (int i = 0; i < kPts; ++i) {
+        k2[i] = f[i];
+        y_new[i] = rk23::new_state(y[i], k0[i], k1[i], k2[i], ctl.h);
+      }
+      phase = 4;
+    } else {
+#pragma unroll
+      for (int i = 0; i < kPts; ++i)
+        q[i] = rk23::scaled_error(y[i], y_new[i], k0[i], k1[i], k2[i], f[i], ctl.h, rtol, atol);
+      const double error_norm = rms(q);
+      if (ctl.error_test(error_norm)) {
+        while (ctl.ti < a.n_times) {
+          const double te = a.times[ctl.ti];
+          if (!(te <= ctl.t_new)) break;
+          const double x = (te - ctl.t) / ctl.h;
+#pragma unroll
+          for (int i = 0; i < kPts; ++i)
+            if (tid + i * kThreads < n)
+              a.y_out[(size_t)ctl.ti * row_stride + off + tid + i * kThreads] =
+                  rk23::dense_output(y[i], k0[i], k1[i], k2[i], f[i], x, ctl.h);
+          ++ctl.ti;
+        }
+#pragma unroll
+        for (int i = 0; i < kPts; ++i) { y[i] = y_new[i]; k0[i] = f[i]; }
+        ctl.advance(t_bound, max_step);
+      }
+      ++attempts;
+      if (ctl.status == rk23::RUNNING && attempts >= a.max_attempts)
+        ctl.status = rk23::ATTEMPT_LIMIT;
+      ctl.begin_attempt(t_bound);
+      phase = 2;
+    }
+  }
+  if (ctl.status != rk23::FINISHED) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int r = ctl.ti; r < a.n_times; ++r)
+#pragma unroll
+      for (int i = 0; i < kPts; ++i)
+        if (tid + i * kThreads < n) a.y_out[(size_t)r * row_stride + off + tid + i * kThreads] = nan;
+  }
+  if (tid == 0) {
+    a.nfev[blockIdx.x] = ctl.nfev;
+    a.status[blockIdx.x] = ctl.status;
+  }
+}
+
+// out[r][x] = sum_j kernel[(x - j) mod N] in[r][j]: duckarray.smoothing_filter
+// (irfft(sigma * rfft(x)), duckarray.py:116-128) with kernel = that call applied
+// to a unit impulse.  One workgroup per row; in-place (out == in) is allowed.
+__global__ __launch_bounds__(kThreads) void circulant_apply_kernel(
+    const double* __restrict__ kernel, const double* in, double* out, int n) {
+  extern __shared__ __attribute__((aligned(16))) double smem64[];
+  double* x = smem64;
+  double* c = smem64 + n;
+  const size_t off = (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += kThreads) { x[i] = in[off + i]; c[i] = kernel[i]; }
+  __syncthreads();
+  for (int pos = threadIdx.x; pos < n; pos += kThreads) {
+    double acc = 0.0;
+    int idx = pos;
+    for (int j = 0; j < n; ++j) {
+      acc = fma(c[idx], x[j], acc);
+      idx = idx == 0 ? n - 1 : idx - 1;
+    }
+    out[off + pos] = acc;
   }
 }
 

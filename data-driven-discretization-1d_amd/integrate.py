@@ -6,6 +6,7 @@ Mirror of ``pde_superresolution/integrate.py`` for the learned-stencil path:
   SavedModelDifferentiator       integrate.py:48-71   (HIP model instead of a TF session)
   PolynomialDifferentiator       integrate.py:74-105
   odeint                         integrate.py:143-169 (SciPy RK23, max_step 0.01)
+  integrate_exact_batch          integrate_exact for a batch, entirely on the device
   SpectralDifferentiator         integrate.py:108-121 (float64 circulant kernel)
   WENODifferentiator             integrate.py:124-140
   odeint_with_periodic_filtering integrate.py:172-212
@@ -23,7 +24,6 @@ per-sample loop (run_evaluation.py:152-174) becomes on one MI355X.
 Results are ``xarray.Dataset`` objects when xarray is importable, otherwise a
 ``Dataset`` stand-in exposing the same ``data_vars`` / ``coords`` mapping.
 """
-import functools
 import logging
 from typing import Optional, Tuple
 
@@ -213,51 +213,143 @@ def exact_differentiator(equation) -> Differentiator:
   raise TypeError('unexpected equation: {}'.format(equation))
 
 
+# ---------------------------------------------------------------------------
+# Solvers.  The reference has one execution shape -- SciPy on the host driving a
+# Differentiator, one sample at a time.  Here the same drivers (plain solve,
+# segmented solve with the low-pass filter between segments, warm-up) are
+# written once over a small solver interface with two implementations: the
+# host one (SciPy, any Differentiator, one sample) and the device one (the
+# batched on-device RK23 of ddd_integrate_adaptive_f64 + the circulant filter
+# kernel, whole batches, nothing leaves the GPU between segments).
+# ---------------------------------------------------------------------------
+class _HostSolver(object):
+  """scipy.integrate.solve_ivp(max_step=0.01) over a Differentiator: one sample,
+  state [x], trajectories [time, x] (integrate.py:143-169)."""
+
+  def __init__(self, differentiator: Differentiator, method: str = 'RK23'):
+    self.differentiator = differentiator
+    self.method = method
+
+  def solve(self, y0, times):
+    import scipy.integrate
+    logging.info('solve_ivp from %s to %s', times[0], times[-1])
+    sol = scipy.integrate.solve_ivp(self.differentiator, (times[0], times[-1]), y0,
+                                    t_eval=times, max_step=0.01, method=self.method)
+    logging.info('nfev: %r, njev: %r, nlu: %r; status: %r, message: %s', sol.nfev,
+                 sol.njev, sol.nlu, sol.status, sol.message)
+    y = sol.y.T   # (time, x)
+    if y.shape[0] < len(times):   # the solver gave up: NaN rows, not an exception
+      logging.info('padding with %s values', len(times) - y.shape[0])
+      y = np.concatenate([y, np.full((len(times) - y.shape[0], y.shape[1]), np.nan)])
+    return y, sol.nfev
+
+  @staticmethod
+  def smooth(y, order):
+    return duckarray.smoothing_filter(y, order=order)
+
+  @staticmethod
+  def last(y):
+    return y[-1]
+
+  @staticmethod
+  def join(pieces):
+    return np.concatenate(pieces, axis=0)
+
+
+class _DeviceSolver(object):
+  """The same for a batch on the GPU: state [batch, x] and trajectories
+  [time, batch, x] are device tensors, nfev is a per-sample device tensor."""
+
+  def __init__(self, device_model, max_step: float = 0.01):
+    self.model = device_model
+    self.max_step = max_step
+    self._filters = {}
+
+  def solve(self, y0, times):
+    y, nfev, _ = self.model.integrate_adaptive(y0, times, max_step=self.max_step)
+    return y, nfev.to(_lib._torch().int64)
+
+  def smooth(self, y, order):
+    n = y.shape[-1]
+    if order not in self._filters:   # the filter applied to a unit impulse, uploaded once
+      impulse = np.zeros(n)
+      impulse[0] = 1.0
+      self._filters[order] = _lib.as_device(duckarray.smoothing_filter(impulse, order=order))
+    return _lib.circulant_apply(self._filters[order], y)
+
+  @staticmethod
+  def last(y):
+    return y[-1]
+
+  @staticmethod
+  def join(pieces):
+    return _lib._torch().cat(pieces, dim=0)
+
+
+def _filter_segments(times: np.ndarray, filter_interval: float):
+  """Index ranges [start - 1, stop) of ``times`` between consecutive filter
+  times (integrate.py:191-199); every filter time must be an output time."""
+  boundaries = np.arange(times[0], times[-1] + 1e-8, filter_interval)
+  if not np.isin(boundaries, times).all():
+    raise ValueError('all times in filter_interval must be sampled')
+  cuts = np.searchsorted(times, boundaries, side='right')
+  return [(int(a) - 1, int(b)) for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def _solve_with_filtering(solver, y0, times, filter_interval, filter_order):
+  """integrate.py:172-212 over either solver: integrate segment by segment,
+  pass the state through the smoothing filter between segments (spectral methods
+  for hyperbolic problems alias) and filter the saved trajectory once at the end
+  -- filtering every saved step during integration would add noise."""
+  pieces = [y0[None]]
+  num_evals = 0
+  for first, stop in _filter_segments(times, filter_interval):
+    segment, evals = solver.solve(y0, times[first:stop])
+    pieces.append(segment[1:])   # its first row repeats y0
+    y0 = solver.smooth(solver.last(segment), filter_order)
+    num_evals = num_evals + evals
+  y = solver.join(pieces)
+  assert y.shape[0] == times.size
+  return solver.smooth(y, filter_order), num_evals
+
+
+def _solve(solver, equation, initial_state, times, warmup, filter_interval,
+           filter_all_times, exact_solver=None, resample=None):
+  """integrate.py:238-279 over either solver: optional warm-up with the exact
+  solver (filtered every ``filter_interval`` if given), then the run itself."""
+  filter_order = (max(equation.to_exact().DERIVATIVE_ORDERS)
+                  if filter_interval is not None else None)
+
+  def run(which, y0, run_times, filtered):
+    if filtered:
+      return _solve_with_filtering(which, y0, run_times, filter_interval, filter_order)
+    return which.solve(y0, run_times)
+
+  if warmup:
+    warmup_times = (np.arange(0, warmup + 1e-8, filter_interval)
+                    if filter_interval is not None else np.array([0, warmup]))
+    warm, _ = run(exact_solver, initial_state, warmup_times, filter_interval is not None)
+    # the state after warm-up, on this equation's grid, starts the run
+    y0 = resample(exact_solver.last(warm))
+  else:
+    y0 = initial_state
+  return run(solver, y0, warmup + times, filter_all_times and filter_interval is not None)
+
+
 def odeint(y0: np.ndarray, differentiator: Differentiator, times: np.ndarray,
            method: str = 'RK23') -> Tuple[np.ndarray, int]:
-  """integrate.py:143-169: SciPy solve_ivp, max_step 0.01, NaN-pad on failure."""
-  import scipy.integrate
-  logging.info('solve_ivp from %s to %s', times[0], times[-1])
-  sol = scipy.integrate.solve_ivp(differentiator, (times[0], times[-1]), y0,
-                                  t_eval=times, max_step=0.01, method=method)
-  y = sol.y.T   # (time, x)
-  logging.info('nfev: %r, njev: %r, nlu: %r', sol.nfev, sol.njev, sol.nlu)
-  logging.info('status: %r, message: %s', sol.status, sol.message)
-  num_missing = len(times) - y.shape[0]
-  if num_missing:
-    logging.info('padding with %s values', num_missing)
-    y = np.pad(y, ((0, num_missing), (0, 0)), mode='constant',
-               constant_values=np.nan)
-  return y, sol.nfev
+  """integrate.py:143-169: SciPy solve_ivp, max_step 0.01, NaN rows on failure."""
+  return _HostSolver(differentiator, method).solve(y0, times)
 
 
 def odeint_with_periodic_filtering(y0: np.ndarray,
                                    differentiator: Differentiator,
                                    times: np.ndarray, filter_interval: float,
                                    filter_order: int, method: str = 'RK23'):
-  """Integrate in segments, low-pass filtering between them (integrate.py:172-212).
-
-  Spectral methods for hyperbolic problems alias; every ``filter_interval`` the
-  state is passed through ``duckarray.smoothing_filter`` and the saved
-  trajectory is filtered once more at the end.
-  """
-  eps = 1e-8
-  split_times = np.arange(times[0], times[-1] + eps, filter_interval)
-  if not np.isin(split_times, times).all():
-    raise ValueError('all times in filter_interval must be sampled')
-  split_indexes = np.searchsorted(times, split_times, side='right')
-  pieces = [y0[np.newaxis, ...]]
-  num_evals = 0
-  for start, stop in zip(split_indexes[:-1], split_indexes[1:]):
-    segment, segment_evals = odeint(y0, differentiator, times[start - 1:stop],
-                                    method=method)
-    pieces.append(segment[1:])   # the first row repeats y0
-    y0 = duckarray.smoothing_filter(segment[-1], order=filter_order)
-    num_evals += segment_evals
-  y = np.concatenate(pieces, axis=0)
-  assert y.shape == (times.size, y0.size)
-  # filtering every saved step during integration would add noise; do it once
-  return duckarray.smoothing_filter(y, order=filter_order), num_evals
+  """integrate.py:172-212: segments of ``odeint`` with ``duckarray.smoothing_filter``
+  between them and over the saved trajectory."""
+  return _solve_with_filtering(_HostSolver(differentiator, method), y0, times,
+                               filter_interval, filter_order)
 
 
 def integrate(equation, differentiator: Differentiator,
@@ -266,33 +358,59 @@ def integrate(equation, differentiator: Differentiator,
               filter_all_times: bool = False):
   """Integrate with optional exact warm-up and periodic filtering
   (integrate.py:238-279)."""
-  if filter_interval is not None:
-    warmup_odeint = functools.partial(
-        odeint_with_periodic_filtering, filter_interval=filter_interval,
-        filter_order=max(equation.to_exact().DERIVATIVE_ORDERS))
-  else:
-    warmup_odeint = odeint
+  exact_solver = None
+  initial_state = None
   if warmup:
     equation_exact = equation.to_exact()
-    diff_exact = exact_differentiator(equation_exact)
-    if filter_interval is not None:
-      warmup_times = np.arange(0, warmup + 1e-8, filter_interval)
-    else:
-      warmup_times = np.array([0, warmup])
-    solution_warmup, _ = warmup_odeint(equation_exact.initial_value(),
-                                       diff_exact, times=warmup_times,
-                                       method=integrate_method)
-    # the state after warm-up, on this equation's grid, starts the run
-    y0 = equation.grid.resample(solution_warmup[-1, :])
+    exact_solver = _HostSolver(exact_differentiator(equation_exact), integrate_method)
+    initial_state = equation_exact.initial_value()
   else:
-    y0 = equation.initial_value()
-  odeint_func = warmup_odeint if filter_all_times else odeint
-  solution, num_evals = odeint_func(y0, differentiator, times=warmup + times,
-                                    method=integrate_method)
+    initial_state = equation.initial_value()
+  solution, num_evals = _solve(
+      _HostSolver(differentiator, integrate_method), equation, initial_state, times,
+      warmup, filter_interval, filter_all_times, exact_solver, equation.grid.resample)
   return _make_dataset(
       data_vars={'y': (('time', 'x'), solution)},
       coords={'time': warmup + times, 'x': equation.grid.solution_x,
               'num_evals': num_evals})
+
+
+def integrate_exact_batch(equations, times: np.ndarray = _DEFAULT_TIMES,
+                          warmup: float = 0, filter_interval: float = None):
+  """``integrate_exact`` (integrate.py:282-293) for many samples at once, on the
+  device from start to end: what ``scripts/create_exact_data.py`` maps over
+  random seeds, for the equations whose exact method is spectral (KdV, KS).
+
+  ``equations``: same type, same grid, one per sample (they differ by
+  ``random_seed``, i.e. by initial condition).  Every sample is advanced by its
+  own SciPy-identical RK23 controller over the float64 spectral right-hand side
+  (``ddd_integrate_adaptive_f64`` on a spectral model); with ``filter_interval``
+  the state passes through the smoothing filter between segments and the saved
+  trajectory once at the end, as a circulant kernel on the device
+  (``ddd_circulant_apply_f64``).  Returns a Dataset with y [sample, time, x]
+  float64 and per-sample num_evals.
+  """
+  exact = [eq.to_exact() for eq in equations]
+  first = exact[0]
+  if first.EXACT_METHOD is not equations_lib.ExactMethod.SPECTRAL:
+    raise ValueError('integrate_exact_batch covers the spectral exact solvers (KdV, KS); '
+                     'use integrate_exact per sample for {}'.format(type(first).__name__))
+  for eq in exact[1:]:
+    if type(eq) is not type(first) or (eq.grid.solution_num_points, eq.grid.period) != (
+        first.grid.solution_num_points, first.grid.period):
+      raise ValueError('all equations must share their type and grid')
+  solver = _DeviceSolver(model_lib.SpectralModel(first, convention='fftpack'))
+  y0 = _lib.as_device(np.stack([eq.initial_value() for eq in exact]),
+                      _lib._torch().float64)
+  solution, num_evals = _solve(solver, first, y0, np.asarray(times, dtype=np.float64),
+                               warmup, filter_interval, False, solver,
+                               lambda state: state)   # exact grid == its own grid
+  return _make_dataset(
+      data_vars={'y': (('sample', 'time', 'x'),
+                       solution.permute(1, 0, 2).contiguous().cpu().numpy())},
+      coords={'time': warmup + np.asarray(times), 'x': first.grid.solution_x,
+              'sample': np.arange(len(exact)),
+              'num_evals': ('sample', num_evals.cpu().numpy())})
 
 
 def integrate_exact(equation, times: np.ndarray = _DEFAULT_TIMES,

@@ -267,8 +267,10 @@ int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
  *          (a safety net SciPy does not have; <= 0 selects a default of 1000x
  *          the attempts of a run at max_step).  Rows a failed sample did not
  *          reach are NaN, as integrate.odeint pads them (integrate.py:161-167).
- * MFMA-path models only (ddd_kernel_name "mfma_f32_*"); others return
- * DDD_ERR_UNSUPPORTED and keep the one-sample SciPy route over
+ * MFMA-path models (ddd_kernel_name "mfma_f32_*") and spectral models
+ * (ddd_spectral_create: integrate.odeint over SpectralDifferentiator, the
+ * "exact" KdV / KS solver, integrate.py:108-121, with a float64 right-hand side);
+ * others return DDD_ERR_UNSUPPORTED and keep the one-sample SciPy route over
  * ddd_time_derivative. */
 int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
                                int n_times, double rtol, double atol,
@@ -289,6 +291,17 @@ int ddd_rk_substep_f64(ddd_model* model, double t, const double* y_in,
                        const double* y_base, double c1, double* y_out,
                        const double* acc_in, double c2, double* acc_out,
                        int batch, void* stream);
+
+/* Replaces: duckarray.smoothing_filter (duckarray.py:116-128), the low-pass
+ * filter odeint_with_periodic_filtering (integrate.py:172-212) applies to the
+ * state between segments and to the saved trajectory -- and any other
+ * translation-invariant linear operator on the periodic grid.  Float64.
+ *   out[r][x] = sum_j kernel[(x - j) mod n] * in[r][j],   r < rows
+ * `kernel` [n] (device) is the operator applied to a unit impulse at x = 0
+ * (smoothing_filter(delta, alpha, order)); in / out [rows][n]; out may alias in.
+ * n <= 2048. */
+int ddd_circulant_apply_f64(const double* kernel, const double* in, double* out,
+                            int rows, int n, void* stream);
 
 /* ---- parity / debugging views of the same kernel ------------------------ */
 

@@ -229,3 +229,76 @@ def test_integrate_exact_baseline_and_model():
 def _y_named(ds, name):
   v = ds.data_vars[name]
   return np.asarray(v[1] if isinstance(v, tuple) else v)
+
+
+# ---------------------------------------------------------------------------
+# The exact spectral solver entirely on the device: batched adaptive RK23 over
+# the float64 right-hand side + the smoothing filter as a circulant kernel
+# ---------------------------------------------------------------------------
+def test_smoothing_filter_on_device_vs_reference(exact):
+  """duckarray.smoothing_filter (duckarray.py:116-128) as ddd_circulant_apply_f64
+  against the reference's own outputs."""
+  from ddd1d_amd import _lib, duckarray
+  x = exact['spectral_derivative/x']
+  impulse = np.zeros(x.shape[-1])
+  impulse[0] = 1.0
+  for order in (2, 3, 4):
+    kernel = duckarray.smoothing_filter(impulse, order=order)
+    got = _lib.circulant_apply(kernel, x).cpu().numpy()
+    want = exact['smoothing_filter/order%d' % order]
+    assert got.shape == want.shape
+    assert rel_err(got, want) < 1e-12, order
+  # batches of trajectories [time, sample, x], in one launch
+  stacked = np.stack([x, 2 * x, -x])
+  got = _lib.circulant_apply(duckarray.smoothing_filter(impulse, order=2), stacked).cpu().numpy()
+  assert rel_err(got, duckarray.smoothing_filter(stacked, order=2)) < 1e-12
+
+
+def test_integrate_exact_batch_vs_reference_and_per_sample(exact):
+  """integrate_exact_batch: every sample with its own RK23 controller over the
+  float64 spectral right-hand side, warm-up and periodic filtering on the device.
+  The sample the reference fixture was generated for reproduces the reference's
+  trajectory AND its evaluation count; every sample equals the one-sample host
+  SciPy run over the same kernel (nfev equal, 1e-9)."""
+  times = np.linspace(0, 0.1, 3)
+  eqs = [equations.KdVEquation(64, random_seed=s) for s in (1, 5, 9, 12)]
+  ds = integrate.integrate_exact_batch(eqs, times=times, warmup=0.05)
+  y = _y(ds)
+  nfev = np.asarray(_coord(ds, 'num_evals'))
+  assert y.shape == (4, 3, 64) and y.dtype == np.float64
+  np.testing.assert_allclose(np.asarray(_coord(ds, 'time')), exact['exact/kdv64_warmup/times'])
+  assert rel_err(y[0], exact['exact/kdv64_warmup/y']) < 1e-6
+  assert int(nfev[0]) == int(exact['exact/kdv64_warmup/nfev'])
+  for b in (1, 3):
+    one = integrate.integrate_exact(eqs[b], times=times, warmup=0.05)
+    assert int(np.asarray(_coord(one, 'num_evals'))) == int(nfev[b])
+    assert rel_err(y[b], _y(one)) < 1e-9
+  # periodic filtering: segments + circulant filter, nothing leaves the device
+  times = np.linspace(0, 0.04, 5)
+  eqs = [equations.KSEquation(64, random_seed=s) for s in (2, 3)]
+  ds = integrate.integrate_exact_batch(eqs, times=times, warmup=0.02, filter_interval=0.01)
+  y = _y(ds)
+  nfev = np.asarray(_coord(ds, 'num_evals'))
+  assert rel_err(y[0], exact['exact/ks64_filtered/y']) < 1e-6
+  assert int(nfev[0]) == int(exact['exact/ks64_filtered/nfev'])
+  one = integrate.integrate_exact(eqs[1], times=times, warmup=0.02, filter_interval=0.01)
+  assert int(np.asarray(_coord(one, 'num_evals'))) == int(nfev[1])
+  assert rel_err(y[1], _y(one)) < 1e-9
+  with pytest.raises(ValueError):
+    integrate.integrate_exact_batch([equations.BurgersEquation(64)], times=times)
+
+
+def test_spectral_adaptive_large_grid_and_failure():
+  """N = 512 (two grid points per thread) and N = 2048 (eight); a sample that
+  blows up stops with status -1 and NaN rows while its neighbours finish."""
+  for n, horizon in ((512, 2e-3), (2048, 2e-5)):
+    eq = equations.KdVEquation(n, random_seed=3)
+    model = model_lib.SpectralModel(eq)
+    y0 = np.stack([eq.initial_value(), 0.5 * eq.initial_value()])
+    times = np.linspace(0, horizon, 3)
+    y, nfev, status = model.integrate_adaptive(y0, times)
+    diff = integrate.SpectralDifferentiator(eq)
+    for b in range(2):
+      want, want_nfev = integrate.odeint(y0[b], diff, times)
+      assert int(nfev[b]) == want_nfev and int(status[b]) == 0, (n, b, int(nfev[b]), want_nfev)
+      assert rel_err(y[:, b].cpu().numpy(), want) < 1e-9
