@@ -173,7 +173,8 @@ struct ddd_model {
   float* d_w_input = nullptr;
   float* d_w_hidden = nullptr;
   float* d_w_final4 = nullptr;
-  float* d_w_final4_pad = nullptr;
+  float* d_w_final4_rt = nullptr;
+  bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
   float* d_trig = nullptr;
@@ -253,9 +254,13 @@ void fill_equation(const ddd_config& cfg, ddd::DevParams* dp) {
   dp->conservative = is_conservative(cfg.equation) ? 1 : 0;
 }
 
-// Tables zero-padded to 8 stencil columns for the MFMA-path epilogue; they
-// travel inside DevParams (kernel-argument segment).
-int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias) {
+// Projection tables zero-padded to the kernels' stencil columns for the
+// MFMA-path epilogue; they travel inside DevParams (kernel-argument segment).
+// `identity`: polynomial_accuracy_order = 0 on the wide kernels -- output channel
+// G d + g IS coefficient g of derivative d (model.py:460-475), expressed as a
+// projection with unit rows and zero bias so that the unfolded epilogue applies.
+int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias,
+                         bool identity = false) {
   ddd::DevParams& dp = m->dp;
   std::memset(dp.ns8, 0, sizeof(dp.ns8));
   std::memset(dp.bias8, 0, sizeof(dp.bias8));
@@ -264,11 +269,19 @@ int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias
   if (bias != nullptr)
     for (int d = 0; d < dp.D; ++d)
       for (int g = 0; g < dp.G; ++g) dp.bias8[d][g] = bias[d * dp.G + g];
-  if (nullspace != nullptr) {
+  if (identity) {
+    for (int d = 0; d < dp.D; ++d)
+      for (int g = 0; g < dp.G; ++g) {
+        const int c = d * dp.G + g;
+        dp.dsel_bits |= (unsigned long long)d << (2 * c);
+        dp.dsel_valid |= 1u << c;
+        dp.ns8[c][g] = 1.0f;
+      }
+  } else if (nullspace != nullptr) {
     for (int d = 0; d < dp.D; ++d)
       for (int j = 0; j < dp.in_size[d]; ++j) {
         const int c = dp.in_start[d] + j;
-        dp.dsel_bits |= (unsigned)d << (2 * c);
+        dp.dsel_bits |= (unsigned long long)d << (2 * c);
         dp.dsel_valid |= 1u << c;
         for (int g = 0; g < dp.G; ++g)
           dp.ns8[c][g] = nullspace[dp.ns_off[d] + j * dp.G + g];
@@ -320,33 +333,35 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     const float* w_nat = weights + dp.w_off[l];   // [5][32][C_out]
     const float* b_nat = weights + dp.b_off[l];
     // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
-    // W'[tap][cin][8 d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
+    // W'[tap][cin][G d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
     // (accumulated in double, rounded once to float32), same for the bias.
-    // The layer then emits the D x 8 coefficient deltas directly and the
-    // epilogue's projection disappears.  Deviation from the reference's
-    // operation order: O(1 ulp) of the deltas, far inside the 1e-5 tolerance.
+    // The layer then emits the D x G coefficients directly and the epilogue's
+    // projection disappears.  Deviation from the reference's operation order:
+    // O(1 ulp) of the coefficient deltas, far inside the 1e-5 tolerance.
+    // (wf / bf: 16 columns, channel G d + g; D <= 2, G <= 8.)
     std::vector<float> wf, bf;
     const bool projected = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao > 0;
     const bool direct_coeffs = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0;
-    bool can_fold = projected && dp.D <= 2 && !g_debug.no_fold;
-    if (direct_coeffs) {
-      // the net emits the D x G coefficients themselves (model.py:460-475): the
-      // same channel layout as a folded layer (8 d + g), nothing to project
+    // the kernels' folded epilogue exists for two derivatives and 6..8 stencil points
+    const bool fold_shape = dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
+    bool can_fold = projected && fold_shape && !g_debug.no_fold;
+    if (direct_coeffs && fold_shape) {
+      // the net emits the D x G coefficients themselves (model.py:460-475) in
+      // exactly the folded layer's channel order: nothing to project
       can_fold = true;
       wf.assign((size_t)5 * 32 * 16, 0.0f);
       bf.assign(16, 0.0f);
-      for (int d = 0; d < dp.D; ++d)
-        for (int g = 0; g < dp.G; ++g) {
-          for (int tc = 0; tc < 5 * 32; ++tc)
-            wf[(size_t)tc * 16 + 8 * d + g] = w_nat[(size_t)tc * dp.C_out + d * dp.G + g];
-          bf[8 * d + g] = b_nat[d * dp.G + g];
-        }
+      for (int c = 0; c < dp.D * dp.G; ++c) {
+        for (int tc = 0; tc < 5 * 32; ++tc)
+          wf[(size_t)tc * 16 + c] = w_nat[(size_t)tc * dp.C_out + c];
+        bf[c] = b_nat[c];
+      }
     } else if (can_fold) {
       wf.assign((size_t)5 * 32 * 16, 0.0f);
       bf.assign(16, 0.0f);
       for (int d = 0; d < dp.D; ++d)
         for (int g = 0; g < dp.G; ++g) {
-          const int oc = 8 * d + g;
+          const int oc = dp.G * d + g;
           for (int tc = 0; tc < 5 * 32; ++tc) {
             double acc = 0.0;
             for (int j = 0; j < dp.in_size[d]; ++j)
@@ -366,8 +381,8 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     // grouped by four; instruction q = k * groups + grp reads lanes
     // 4 (q % 16) .. + 3 of weight register q / 16, lane 4 abid + r carrying
     // channel 4 grp + r; k = (tap, cin) in natural order, k = 160: bias.
-    // `folded`: source = the folded layer (16 channels, 8 d + g), else the
-    // natural one; `renumber`: live channels made contiguous (folded: G d + g).
+    // `folded`: source = the folded layer (16 columns, channel G d + g), else the
+    // natural one; `renumber`: only the live channels.
     auto pack4 = [&](int groups, bool folded, bool renumber) {
       const float* w = folded ? wf.data() : w_nat;
       const float* b = folded ? bf.data() : b_nat;
@@ -380,10 +395,7 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
           for (int r = 0; r < 4; ++r) {
             const int ch = 4 * grp + r;
             int src = ch;
-            if (renumber) {
-              if (ch >= n_ch) continue;
-              src = folded ? 8 * (ch / dp.G) + ch % dp.G : ch;
-            }
+            if (renumber && ch >= n_ch) continue;   // folded columns are contiguous already
             if (src >= cout_n) continue;
             packed4[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
                 k < 160 ? w[(size_t)k * cout_n + src] : b[src];
@@ -391,19 +403,55 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
         }
       return packed4;
     };
-    // run-time-parameterised kernels: always four groups, so fold whenever possible
-    m->dp.folded = can_fold ? 1 : 0;
-    int rc = upload(pack4(4, can_fold, false), &m->d_w_final4_pad);
-    if (rc) return rc;
-    m->dp.w_final4_pad = m->d_w_final4_pad;
+    // Run-time-parameterised kernels: the live channel groups are issued two by
+    // two (rhs_mfma.h: a pair = two interleaved accumulator chains at 8.1 cycles
+    // per MFMA, a lone last group 13.2).  Folding the projection trades the
+    // epilogue's ~C_out x G FMAs (~2.5 units of 161 MFMA slots) for D x G
+    // instead of C_out channels: fold only where the matrix work does not grow
+    // by more than that (the same outcome as rhs_mfma.h: spec_folded for the six
+    // default models, so the two kernel families stay bit-identical).
+    // polynomial_accuracy_order = 0 has nothing to project.
+    const auto issue_cost = [](int groups) { return 16.2 * (groups / 2) + 13.2 * (groups % 2); };
+    const int groups_rt_plain = (dp.C_out + 3) / 4;
+    const int groups_rt_folded = (dp.D * dp.G + 3) / 4;
+    const bool fold_rt = can_fold && (direct_coeffs || issue_cost(groups_rt_folded) <=
+                                                           issue_cost(groups_rt_plain) + 2.5);
+    m->dp.folded = fold_rt ? 1 : 0;
+    m->dp.rt_groups = fold_rt ? groups_rt_folded : groups_rt_plain;
+    {
+      const float* w = fold_rt ? wf.data() : w_nat;
+      const float* b = fold_rt ? bf.data() : b_nat;
+      const int cout_n = fold_rt ? 16 : dp.C_out;
+      const int pairs = (m->dp.rt_groups + 1) / 2, pair_rows = ddd::mfma::fin4_regs(2);
+      std::vector<float> packed((size_t)pairs * pair_rows * 64, 0.0f);
+      for (int gp = 0; gp < pairs; ++gp) {
+        const int ng = std::min(2, m->dp.rt_groups - 2 * gp);   // 2, or a lone last group
+        for (int k = 0; k < ddd::mfma::kFin4K; ++k)
+          for (int gi = 0; gi < ng; ++gi) {
+            const int q = k * ng + gi;
+            for (int r = 0; r < 4; ++r) {
+              const int ch = 4 * (2 * gp + gi) + r;
+              if (ch >= cout_n) continue;
+              packed[((size_t)gp * pair_rows + q / 16) * 64 + 4 * (q % 16) + r] =
+                  k < 160 ? w[(size_t)k * cout_n + ch] : b[ch];
+            }
+          }
+      }
+      int rc2 = upload(packed, &m->d_w_final4_rt);
+      if (rc2) return rc2;
+      m->dp.w_final4_rt = m->d_w_final4_rt;
+    }
+    int rc = DDD_OK;
     // specialised kernels: live channels only; folded only where that does not
     // cost a channel group (same rule as rhs_mfma.h: spec_folded)
     const int groups_folded = (dp.D * dp.G + 3) / 4, groups_plain = (dp.C_out + 3) / 4;
     m->spec_folded = can_fold && groups_folded <= groups_plain;
     m->dp.fin4_groups = m->spec_folded ? groups_folded : groups_plain;
-    rc = upload(pack4(m->dp.fin4_groups, m->spec_folded, true), &m->d_w_final4);
-    if (rc) return rc;
-    m->dp.w_final4 = m->d_w_final4;
+    if (!m->wide) {   // (the specialised kernels never serve a wide model)
+      rc = upload(pack4(m->dp.fin4_groups, m->spec_folded, true), &m->d_w_final4);
+      if (rc) return rc;
+      m->dp.w_final4 = m->d_w_final4;
+    }
   }
   return DDD_OK;
 }
@@ -414,19 +462,27 @@ void decide_mfma(ddd_model* m) {
   bool ok = true;
   auto no = [&](const char* msg) { if (ok) snprintf(why, sizeof(why), "%s", msg); ok = false; };
   if (dp.N < 8 || dp.N > 256) no("num_points outside [8, 256]");
-  if (dp.G > ddd::kGMax) no("stencil wider than 8");
+  if (dp.G > ddd::kGWide) no("stencil wider than 12");
+  if (dp.G > dp.N) no("stencil wider than the grid");
   if (dp.fixed && dp.weno) no("WENO reconstruction");
+  // The wide flavour of the run-time-parameterised kernels (stencils up to 12
+  // points, up to 24 output channels, projection in the epilogue) carries what
+  // the default flavour (8 points, 16 channels) cannot: coefficient_grid_min_size
+  // = 9 and polynomial_accuracy_order = 0 with three derivatives
+  // (training_test.py:56-57).
+  bool wide = dp.G > ddd::kGMax;
   if (!dp.fixed) {
     // direct heads (space_derivatives / time_derivative / flux: D or 1 output
     // channels) and polynomial_accuracy_order = 0 (D x G coefficient channels,
     // no projection) run on the run-time-parameterised MFMA kernels
-    if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2)
-      no("polynomial_accuracy_order 0 with more than two derivatives");
+    if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2) wide = true;
+    if (dp.C_out > ddd::kChMax) wide = true;
     if (dp.F != ddd::mfma::kF) no("filter_size != 32");
     if (dp.K != ddd::mfma::kKW) no("kernel_size != 5");
     if (dp.L < 2) no("fewer than 2 conv layers");
-    if (dp.C_out > 16) no("more than 16 output channels");
+    if (dp.C_out > ddd::kChWide) no("more than 24 output channels");
   }
+  m->wide = ok && wide;
   m->mfma_ok = ok;
   m->mfma_reason = why;
   m->kernel = ok ? DDD_KERNEL_MFMA : DDD_KERNEL_GENERIC;
@@ -506,7 +562,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   const bool fits64 = m->dp.N <= 64 && 64 % m->dp.N == 0;
   if (m->force_rows == 256 || !fits64) return {256, 64};
   if (m->force_rows == 64) return {64, 64};
-  if (m->force_rows == 32) return {64, 32};
+  if (m->force_rows == 32 && !m->wide) return {64, 32};   // (no wide two-wave split)
   // Measured on MI355X (profiles/r1_ablation.txt): two 32-row wavefronts per
   // SIMD are slower than one 64-row wavefront even when the batch leaves half
   // the wave slots empty (B = 1024: 73.6 vs 82.1 TFLOP/s), so the split is
@@ -520,7 +576,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
 // width, projection folded when D <= 2) on a non-Godunov equation.
 int spec_equation(const ddd_model* m, int rows) {
   const ddd::DevParams& dp = m->dp;
-  if (g_debug.no_spec) return -1;
+  if (g_debug.no_spec || m->wide) return -1;
   if (dp.forced) {
     // the specialised kernels only carry the harmonic-sum forcing (rhs_mfma.h:
     // launch_setup `fast`); exotic tables go to the run-time kernels
@@ -595,7 +651,12 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
       DDD_SUBSTEP_CASE(ddd::EQ_KS)
       DDD_SUBSTEP_CASE(ddd::EQ_KS_CONS)
       default:
-        ddd::launch::substep_runtime(geo.rows, geo.wave_rows, m->dp, a, blocks, stream);
+        if (m->wide) {
+          if (geo.rows == 64) ddd::launch::substep_wide_unit<64>(m->dp, a, blocks, stream);
+          else ddd::launch::substep_wide_unit<256>(m->dp, a, blocks, stream);
+        } else {
+          ddd::launch::substep_runtime(geo.rows, geo.wave_rows, m->dp, a, blocks, stream);
+        }
     }
 #undef DDD_SUBSTEP_CASE
   } else {
@@ -643,6 +704,11 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
     default: break;
   }
 #undef DDD_SPEC_CASE
+  if (m->wide) {
+    if (kWR == 64) ddd::launch::integrate_wide_unit<kRows, f64 ? 1 : 0>(hoist, m->dp, a, blocks,
+                                                                        stream);
+    return;
+  }
   ddd::launch::integrate_runtime(kRows, kWR, f64, hoist, m->dp, a, blocks, stream);
 }
 
@@ -805,7 +871,10 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   if (!rc) {
     decide_mfma(m);
     if (m->mfma_ok) {
-      rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr);
+      const bool fold_shape = dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
+      rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr,
+                                dp.target == ddd::TARGET_COEFFICIENTS && !projected &&
+                                    !fold_shape);
       if (!rc) rc = pack_mfma_weights(m, weights);
     }
   }
@@ -844,7 +913,7 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils, size_t n_s
   if (!rc) {
     decide_mfma(m);
     // the padded stencil table also feeds the streaming kernel (any N <= 1024)
-    if (m->mfma_ok || m->dp.G <= ddd::kGMax) rc = upload_padded_tables(m, nullptr, stencils);
+    if (m->mfma_ok || m->dp.G <= ddd::kGWide) rc = upload_padded_tables(m, nullptr, stencils);
   }
   if (rc) { ddd_model_destroy(m); return rc; }
   *out = m;
@@ -935,7 +1004,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_final4); free_dev(m->d_w_final4_pad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   free_dev(m->d_times);
@@ -1286,8 +1355,14 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     DDD_ADAPTIVE_CASE(ddd::EQ_KS_CONS)
 #undef DDD_ADAPTIVE_CASE
     default:
-      if (geo.rows == 64) ddd::launch::adaptive_runtime_unit<64>(m->dp, a, blocks, stream);
-      else ddd::launch::adaptive_runtime_unit<256>(m->dp, a, blocks, stream);
+      if (m->wide) {
+        if (geo.rows == 64) ddd::launch::adaptive_wide_unit<64>(m->dp, a, blocks, stream);
+        else ddd::launch::adaptive_wide_unit<256>(m->dp, a, blocks, stream);
+      } else if (geo.rows == 64) {
+        ddd::launch::adaptive_runtime_unit<64>(m->dp, a, blocks, stream);
+      } else {
+        ddd::launch::adaptive_runtime_unit<256>(m->dp, a, blocks, stream);
+      }
   }
   DDD_HIP(hipGetLastError());
   return DDD_OK;
@@ -1424,6 +1499,9 @@ int ddd_set_kernel(ddd_model* m, int kind) {
       if (!m->mfma_ok)
         return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
                     m->mfma_reason.c_str());
+      if (kind == DDD_KERNEL_MFMA_ROWS64_W32 && m->wide)
+        return fail(DDD_ERR_UNSUPPORTED,
+                    "the two-wave split has no wide (stencil > 8 / > 16 channels) instantiation");
       if ((kind == DDD_KERNEL_MFMA_ROWS64 || kind == DDD_KERNEL_MFMA_ROWS64_W32) &&
           !(m->dp.N <= 64 && 64 % m->dp.N == 0))
         return fail(DDD_ERR_UNSUPPORTED,

@@ -8,7 +8,12 @@ namespace ddd {
 constexpr int kMaxDerivs = 4;
 constexpr int kMaxLayers = 8;
 constexpr int kMaxStages = 4;
-constexpr int kGMax = 8;      // widest stencil the MFMA path handles
+constexpr int kGMax = 8;      // widest stencil of the default MFMA kernels (and the stream kernel)
+// "wide" run-time-parameterised MFMA kernels (rhs_mfma.h, kWide): stencils up
+// to 12 points and up to 24 output channels -- coefficient_grid_min_size = 9 and
+// polynomial_accuracy_order = 0 with three derivatives (training_test.py:56-57)
+constexpr int kGWide = 12;
+constexpr int kChMax = 16, kChWide = 24;
 constexpr int kTraceSlots = 256;
 constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
 
@@ -45,22 +50,29 @@ struct DevParams {
   // that rows arrive as scalar (SGPR) operands: for output channel c of the
   // conv tower, ns8[c] is its null-space row zero-padded to 8 stencil columns
   // and dsel the derivative it feeds; bias8[d] likewise.
-  float ns8[16][kGMax];
-  float bias8[kMaxDerivs][kGMax];
+  // (sized for the wide kernels; the default ones use the first 16 rows / 8 columns)
+  float ns8[kChWide][kGWide];
+  float bias8[kMaxDerivs][kGWide];
   // dsel packed: 2 bits per channel (derivative index) + validity mask, so the
-  // hot loop tests one scalar register instead of indexing a 16-SGPR tuple.
-  unsigned dsel_bits, dsel_valid;
-  // folded = 1: w_final4_pad already contains the null-space projection
-  // (W3 @ nullspace), so its output channel 8 d + g IS the coefficient delta of
-  // derivative d, stencil column g (D <= 2 only; run-time-parameterised kernels.
-  // The specialised kernels know at compile time whether w_final4 is folded:
-  // rhs_mfma.h spec_folded).
+  // hot loop tests one scalar register instead of indexing an SGPR tuple.
+  unsigned long long dsel_bits;
+  unsigned dsel_valid;
+  // folded = 1: w_final4_rt already contains the null-space projection
+  // (W3 @ nullspace) -- or the net emits the coefficients themselves
+  // (polynomial_accuracy_order 0) --, so its output channel G d + g IS
+  // coefficient g of derivative d (D <= 2, G in 6..8; run-time-parameterised
+  // kernels.  The specialised kernels know at compile time whether w_final4 is
+  // folded: rhs_mfma.h spec_folded).
   int folded;
   const float* w_input;    // MFMA-packed input layer, 3 x 64
   const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
   // output layer packed for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4), 41 x 64:
   const float* w_final4;      // live channels renumbered contiguously, ceil(channels / 4) groups
-  const float* w_final4_pad;  // 16 channels in natural / 8 d + g numbering, 4 groups
+  // run-time-parameterised kernels: the live channel groups packed two by two
+  // (pair gp: fin4_regs(2) rows for groups 2 gp, 2 gp + 1; an odd last group:
+  // fin4_regs(1) rows), channels in natural / G d + g (folded) numbering
+  const float* w_final4_rt;
+  int rt_groups;              // live channel groups of w_final4_rt
   int fin4_groups;            // groups of w_final4
   // per-sample forcing
   int forced, P, n_k, forcing_batch;

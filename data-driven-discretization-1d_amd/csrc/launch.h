@@ -71,6 +71,29 @@ DDD_DECLARE_RT(64, 32)
 DDD_DECLARE_RT(256, 64)
 #undef DDD_DECLARE_RT
 
+// "wide" flavour (stencils up to 12 points, up to 24 output channels; rhs_mfma.h
+// kWide), 64-row wavefronts only: -DDDD_RT_WIDE=1 units
+template <int kRows, int kF64>
+void integrate_wide_unit(bool hoist, const DevParams& p, const IntegrateArgs& a, int blocks,
+                         hipStream_t stream);
+template <int kRows>
+void substep_wide_unit(const DevParams& p, const SubstepArgs& a, int blocks, hipStream_t stream);
+template <int kRows>
+void adaptive_wide_unit(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                        hipStream_t stream);
+#define DDD_DECLARE_WIDE(ROWS)                                                                \
+  template <> void integrate_wide_unit<ROWS, 0>(bool, const DevParams&, const IntegrateArgs&, \
+                                                int, hipStream_t);                            \
+  template <> void integrate_wide_unit<ROWS, 1>(bool, const DevParams&, const IntegrateArgs&, \
+                                                int, hipStream_t);                            \
+  template <> void substep_wide_unit<ROWS>(const DevParams&, const SubstepArgs&, int,         \
+                                           hipStream_t);                                      \
+  template <> void adaptive_wide_unit<ROWS>(const DevParams&, const AdaptiveArgs&, int,       \
+                                            hipStream_t);
+DDD_DECLARE_WIDE(64)
+DDD_DECLARE_WIDE(256)
+#undef DDD_DECLARE_WIDE
+
 inline void integrate_runtime(int rows, int wave_rows, bool f64, bool hoist, const DevParams& p,
                               const IntegrateArgs& a, int blocks, hipStream_t stream) {
   if (rows == 64 && wave_rows == 64) {

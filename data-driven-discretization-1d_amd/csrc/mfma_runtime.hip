@@ -11,6 +11,9 @@
 #if !defined(DDD_RT_ROWS) || !defined(DDD_RT_WR) || !defined(DDD_RT_F64)
 #error "compile with -DDDD_RT_ROWS=.. -DDDD_RT_WR=.. -DDDD_RT_F64=.."
 #endif
+#ifndef DDD_RT_WIDE
+#define DDD_RT_WIDE 0   // 1: the wide flavour (stencils <= 12, <= 24 output channels)
+#endif
 
 namespace ddd {
 namespace launch {
@@ -21,6 +24,35 @@ typedef double RtState;
 typedef float RtState;
 #endif
 
+#if DDD_RT_WIDE
+template <>
+void integrate_wide_unit<DDD_RT_ROWS, DDD_RT_F64>(bool hoist, const DevParams& p,
+                                                  const IntegrateArgs& a, int blocks,
+                                                  hipStream_t stream) {
+  const dim3 grid(blocks), block(DDD_RT_ROWS);
+  if (hoist)
+    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, true, -1, false, true>),
+                       grid, block, 0, stream, p, a);
+  else
+    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, false, -1, false, true>),
+                       grid, block, 0, stream, p, a);
+}
+#if !DDD_RT_F64
+template <>
+void substep_wide_unit<DDD_RT_ROWS>(const DevParams& p, const SubstepArgs& a, int blocks,
+                                    hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::substep_kernel<DDD_RT_ROWS, 64, -1, true>), dim3(blocks),
+                     dim3(DDD_RT_ROWS), 0, stream, p, a);
+}
+#else
+template <>
+void adaptive_wide_unit<DDD_RT_ROWS>(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                                     hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::adaptive_kernel<DDD_RT_ROWS, 64, false, -1, true>), dim3(blocks),
+                     dim3(DDD_RT_ROWS), 0, stream, p, a);
+}
+#endif
+#else   // !DDD_RT_WIDE
 template <>
 void integrate_runtime_unit<DDD_RT_ROWS, DDD_RT_WR, DDD_RT_F64>(bool hoist, const DevParams& p,
                                                                 const IntegrateArgs& a,
@@ -52,6 +84,8 @@ void adaptive_runtime_unit<DDD_RT_ROWS>(const DevParams& p, const AdaptiveArgs& 
                      dim3(DDD_RT_ROWS), 0, stream, p, a);
 }
 #endif
+
+#endif   // DDD_RT_WIDE
 
 }  // namespace launch
 }  // namespace ddd

@@ -53,10 +53,10 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
   }
 }
 
-template <int kRows, int kWR, bool kHoist, int kEq>
+template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams p,
                                                                        AdaptiveArgs a) {
-  __shared__ Shared<kRows, kWR> sm;
+  __shared__ Shared<kRows, kWR, kWide> sm;
   __shared__ double red[kRows == kWR ? 2 : kRows];
   __shared__ float tev[kRows / 8];   // evaluation time of each sample of the group (N >= 8)
   const int tid = (int)threadIdx.x;

@@ -41,7 +41,13 @@ constexpr int kInSteps = 3;      // (5 taps + bias) / 2
 constexpr int kHidSteps = 81;    // 5*32/2 MFMA steps + 1 bias step
 constexpr int kFin4K = kKW * kF + 1;   // output layer on 4x4x1 MFMAs: 160 reduction steps + bias
 constexpr int kTrigMax = 12;     // 2 * (distinct wavenumbers) kept per lane
-constexpr int kTabRows = 4 + 16; // bias8 rows + one null-space row per output channel
+// Flavours of the run-time-parameterised kernels (template parameter kWide):
+// default: stencils <= 8 points, <= 16 output channels; wide: <= 12 points,
+// <= 24 channels, projection always in the epilogue (never folded).
+__host__ __device__ constexpr int flavour_stencil(bool wide) { return wide ? kGWide : kGMax; }
+__host__ __device__ constexpr int flavour_channels(bool wide) { return wide ? kChWide : kChMax; }
+// projection tables in LDS: 4 bias rows + one null-space row per output channel
+__host__ __device__ constexpr int tab_rows(bool wide) { return 4 + flavour_channels(wide); }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -51,7 +57,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // no cross-wave dependency, wavefronts free-run and eight workgroups share a
 // CU).  Sizes are chosen so that 160 KiB of LDS hold 2 x 256-row or 8 x 64-row
 // workgroups.
-template <int kRows, int kWR = 64>
+template <int kRows, int kWR = 64, bool kWide = false>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
   static constexpr int kFkMax = 3 * kRows / 4;  // samples * 12 harmonic sums (zero padded)
@@ -62,11 +68,14 @@ struct Shared {
   float flux[kRows == kWR ? 1 : kRows];  // one-wave groups exchange flux by shuffle
   float2 pm[kPmMax + 8];          // per (sample, mode): a sin(psi), a cos(psi); + read-ahead padding
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
-  float tab[kTabRows * kGMax];    // [0,4): bias8[d][8]; [4,20): ns8 rows per channel
+  // [0,4): bias rows [d][stencil]; then one null-space row per output channel
+  float tab[tab_rows(kWide) * flavour_stencil(kWide)];
 };
 static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
 static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
 static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
+static_assert(sizeof(Shared<64, 64, true>) <= 22 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
+              "wide flavour: 7 x 64-row / 2 x 256-row workgroups per CU");
 
 // Value the optimiser must treat as unknown: stops loop-invariant code motion
 // from hoisting per-evaluation index math and loads out of the time loop (where
@@ -523,8 +532,8 @@ struct Resident {
 // at the start of the evaluation that uses it.  Inside an evaluation the two
 // phases sit at the input->hidden and hidden->output layer boundaries, where
 // the wavefront otherwise only waits for its activations to land in LDS.
-template <int kRows, int kWR>
-__device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kWide>
+__device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                                const Resident& res, float t, int tid) {
   if (tid < (kRows / p.N) * p.P) {
     float sn, cs;
@@ -538,8 +547,8 @@ __device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows,
 // acc + v and fma(v, 0, acc) is acc for every finite v (the staged values are
 // a sin / a cos of finite angles, the padding is zeroed at setup), so both
 // forms give the same bits.
-template <int kRows, int kWR, bool kMasked = false>
-__device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Resident& res) {
+template <int kRows, int kWR, bool kMasked = false, bool kWide = false>
+__device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR, kWide>& sm, const Resident& res) {
   const int cnt = (res.frc_run >> 16) & 0xff;
   const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm) + (res.frc_run & 0xffff);
   float acc = 0.0f;
@@ -565,8 +574,8 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR>& sm, const Re
   return acc;
 }
 
-template <int kRows, int kWR>
-__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kWide>
+__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
   __syncthreads();
@@ -584,8 +593,8 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 // evaluation after this one) at the layer boundaries.
 // ablate / trace: profiling hooks of libddd1d_probe.so (-DDDD_PROBES); every
 // product call site passes the defaults, so they fold away.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace>
-__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>& sm, int batch,
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide>
+__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR, kWide>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, bool prepare_next = true,
@@ -614,9 +623,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
   // output-channel groups of four (final_layer4): the specialised kernels issue
-  // only the live ones (channels renumbered contiguously, DevParams::w_final4),
-  // the run-time-parameterised kernels all four (w_final4_pad)
-  constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 4;
+  // their live ones as one compile-time interleaved stream (channels renumbered
+  // contiguously, DevParams::w_final4); the run-time-parameterised kernels
+  // issue DevParams::rt_groups live groups two by two (w_final4_rt)
+  constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 2;
+  constexpr int kGW = flavour_stencil(kWide);    // stencil columns carried
+  constexpr int kCh = flavour_channels(kWide);   // output channels carried
+  static_assert(!(kSpec && kWide), "the per-equation kernels have no wide flavour");
   // specialised one-wave integrators keep loop invariants in registers
   constexpr bool kKeepRows = kWR == 64 && kHoist && kEq >= 0;
   const int tid = opaque((int)threadIdx.x);
@@ -666,19 +679,19 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   // Four-wave groups must read them now (other waves rewrite sm.u as soon as
   // they enter the next evaluation); a one-wave group reads them in the
   // epilogue instead and saves 8 registers across the conv tower.
-  float pch[kGMax];
+  float pch[kGW];
   const int gl = nG >> 1;
   if (!kOneWave) {
 #pragma unroll
-    for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g]
+    for (int g = 0; g < kGW; ++g)
+      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g < kGMax ? g : 0]
                                : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
                                       : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
 
-  float net[16];
+  float net[kCh];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) net[c] = 0.0f;
+  for (int c = 0; c < kCh; ++c) net[c] = 0.0f;
   if (!fixed) {
     DDD_STAMP(1);
     if (!(ablate & 16))
@@ -706,7 +719,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
 #pragma unroll
         for (int k = 0; k < kKW; ++k) off4[k] = res.fin4_off[k];
       } else {
-        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_pad) + opaque(ln.lane);
+        // (run-time kernels: the first pair's weights; the next pairs' are
+        // fetched while the previous pair's MFMAs run)
+        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
 #pragma unroll
         for (int s2 = 0; s2 < fin4_regs(kNG); ++s2) wf4[s2] = wsrc[s2 * 64];
         int rows5[kKW];
@@ -723,19 +738,60 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       constexpr bool kMaskedSums = kKeepRows && spec_folded(kSpec ? kEq : 0);
       if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
       __syncthreads();
-      f32x4 acc4[kNG];
-      if (!(ablate & 4)) {
-        final_layer4<kNG>(in, wf4, off4, acc4);
-      } else {
+      if constexpr (kSpec) {
+        f32x4 acc4[kNG];
+        if (!(ablate & 4)) {
+          final_layer4<kNG>(in, wf4, off4, acc4);
+        } else {
 #pragma unroll
-        for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+        // every lane holds its own row's channels: no LDS round trip, no barrier
+#pragma unroll
+        for (int g4 = 0; g4 < kNG; ++g4)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
+      } else if constexpr (!kSpec) {
+        // live groups two by two: a pair is two interleaved accumulator chains
+        // (8.1 cycles per MFMA; a lone chain runs at 13.2, still cheaper than a
+        // padded pair), so a net with 8 channels issues half the matrix work of
+        // one with 16 instead of the same.  Wave-uniform branches.
+        constexpr int kPairRows = fin4_regs(2);
+#pragma unroll
+        for (int gp = 0; gp < kCh / 8; ++gp) {
+          if (2 * gp >= p.rt_groups || (ablate & 4)) break;
+          const bool lone = 2 * gp + 1 >= p.rt_groups;
+          float wnext[kPairRows];
+          if (2 * gp + 2 < p.rt_groups) {   // the following pair's (or lone group's) weights
+            const float* __restrict__ wn =
+                p.w_final4_rt + (size_t)(gp + 1) * kPairRows * 64 + opaque(ln.lane);
+#pragma unroll
+            for (int s2 = 0; s2 < kPairRows; ++s2) wnext[s2] = wn[s2 * 64];
+          }
+          if (!lone) {
+            f32x4 acc2[2];
+            final_layer4<2>(in, wf4, off4, acc2);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+              net[8 * gp + r4] = acc2[0][r4];
+              net[8 * gp + 4 + r4] = acc2[1][r4];
+            }
+          } else {
+            float w1[fin4_regs(1)];
+#pragma unroll
+            for (int s2 = 0; s2 < fin4_regs(1); ++s2) w1[s2] = wf4[s2];
+            f32x4 acc1[1];
+            final_layer4<1>(in, w1, off4, acc1);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) net[8 * gp + r4] = acc1[0][r4];
+          }
+          if (2 * gp + 2 < p.rt_groups) {
+#pragma unroll
+            for (int s2 = 0; s2 < kPairRows; ++s2) wf4[s2] = wnext[s2];
+          }
+        }
       }
       DDD_STAMP(3);
-      // every lane holds its own row's channels: no LDS round trip, no barrier
-#pragma unroll
-      for (int g4 = 0; g4 < kNG; ++g4)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
     }
   } else {
     if (forced && fast_forcing && prepare_next && !(ablate & 1))
@@ -773,52 +829,64 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   }
   if (kOneWave) {
 #pragma unroll
-    for (int g = 0; g < kGMax; ++g)
-      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g]
+    for (int g = 0; g < kGW; ++g)
+      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g < kGMax ? g : 0]
                                : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
                                       : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
-  float cf[kMaxDerivs][kGMax];
+  float cf[kMaxDerivs][kGW];
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d)
 #pragma unroll
-    for (int g = 0; g < kGMax; ++g) cf[d][g] = 0.0f;
-  if (!fixed && folded) {
-    // the output layer already applied the projection: channel G d + g
-    // (specialised kernels, contiguous) or 8 d + g (padded packing)
+    for (int g = 0; g < kGW; ++g) cf[d][g] = 0.0f;
+  if (!fixed && folded && !kWide) {
+    // the output layer already applied the projection (or the net emits the
+    // coefficients themselves, polynomial_accuracy_order 0): channel G d + g,
+    // D <= 2.  Register indices must be compile-time: the run-time kernels
+    // branch (wave-uniformly) over the stencil widths the host folds for, 6..8.
     if (kSpec) {
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g)
+      for (int g = 0; g < kGW; ++g)
         if (g < nG) { cf[0][g] = net[g]; cf[1][g] = net[nG + g]; }
+    } else if (nG == 6) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) { cf[0][g] = net[g]; cf[1][g] = net[6 + g]; }
+    } else if (nG == 7) {
+#pragma unroll
+      for (int g = 0; g < 7; ++g) { cf[0][g] = net[g]; cf[1][g] = net[7 + g]; }
     } else {
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
+      for (int g = 0; g < 8; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
     }
   } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
+    for (int c = 0; c < kCh; ++c) {
       // specialised kernels: the null-space split is known (spec_in_size, checked
       // by capi.hip: spec_equation), so the channel -> derivative map is a
       // compile-time constant
       if (kSpec ? c >= spec_net_channels(kSpec ? kEq : 0) : !((p.dsel_valid >> c) & 1u)) continue;
       const unsigned d = kSpec ? (unsigned)spec_channel_deriv(kSpec ? kEq : 0, c)
-                               : (p.dsel_bits >> (2 * c)) & 3u;
+                               : (unsigned)(p.dsel_bits >> (2 * c)) & 3u;
       const float nv = net[c];
-      const float4 n0 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax);
-      const float4 n1 = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGMax + 4);
-      const float nsr[kGMax] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+      float nsr[kGW];
+#pragma unroll
+      for (int q4 = 0; q4 < kGW / 4; ++q4) {
+        const float4 nq = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGW + 4 * q4);
+        nsr[4 * q4 + 0] = nq.x; nsr[4 * q4 + 1] = nq.y;
+        nsr[4 * q4 + 2] = nq.z; nsr[4 * q4 + 3] = nq.w;
+      }
       if (d == 0) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
+        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
       } else if (d == 1) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
+        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
       } else if (d == 2) {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (!kSpec || g < nG) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
+        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
       } else {
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) cf[3][g] = fmaf(nv, nsr[g], cf[3][g]);
+        for (int g = 0; g < kGW; ++g) cf[3][g] = fmaf(nv, nsr[g], cf[3][g]);
       }
     }
   }
@@ -830,10 +898,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
       if (d >= nD) continue;
       float mean = 0.0f;
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) if (g < nG) mean += cf[d][g];
+      for (int g = 0; g < kGW; ++g) if (g < nG) mean += cf[d][g];
       mean = mean / (float)nG;
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g) if (g < nG) cf[d][g] = cf[d][g] - mean;
+      for (int g = 0; g < kGW; ++g) if (g < nG) cf[d][g] = cf[d][g] - mean;
     }
   }
   float dv[kMaxDerivs];
@@ -846,16 +914,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
         continue;
       }
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g)   // folded: the bias rides in the output layer's bias row
-        if (!folded) cf[d][g] = sm.tab[d * kGMax + g] + cf[d][g];
+      for (int g = 0; g < kGW; ++g)   // folded: the bias rides in the output layer's bias row
+        if (!folded || kWide) cf[d][g] = sm.tab[d * kGW + g] + cf[d][g];
       if (coeffs_out != nullptr && ln.active) {
         float* dst = coeffs_out + ((size_t)ln.gidx * nD + d) * nG;
 #pragma unroll
-        for (int g = 0; g < kGMax; ++g) if (g < nG) dst[g] = cf[d][g];
+        for (int g = 0; g < kGW; ++g) if (g < nG) dst[g] = cf[d][g];
       }
       float s = 0.0f;
 #pragma unroll
-      for (int g = 0; g < kGMax; ++g)
+      for (int g = 0; g < kGW; ++g)
         if (!kSpec || g < nG) s = fmaf(cf[d][g], pch[g], s);   // padded columns: cf = 0
       dv[d] = s;
     }
@@ -918,8 +986,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR>
   return r;
 }
 
-template <int kRows, int kWR>
-__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kWide>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               int block, int batch, Resident& res, bool fast);
 
 // The forcing of this launch can take the harmonic-sum path (else: per-point sinf).
@@ -931,13 +999,14 @@ __device__ __forceinline__ bool forcing_is_fast(const DevParams& p) {
 }
 
 // Per-launch setup, part 1: resident registers and the tables in LDS.
-template <int kRows, int kWR, bool kHoist>
-__device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kHoist, bool kWide>
+__device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               const Lane& ln, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
   const int tid = (int)threadIdx.x;
-  for (int i = tid; i < kTabRows * kGMax; i += kThreads) {
-    const int rowi = i / kGMax, g = i % kGMax;
+  constexpr int kGW = flavour_stencil(kWide);
+  for (int i = tid; i < tab_rows(kWide) * kGW; i += kThreads) {
+    const int rowi = i / kGW, g = i % kGW;
     sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
   const bool fast = forcing_is_fast<kRows, kWR>(p);
@@ -1010,8 +1079,8 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
 }
 
 // Per-launch setup of the persistent integrators and the one-group substep kernel.
-template <int kRows, int kWR, bool kHoist>
-__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kHoist, bool kWide>
+__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                              const Lane& ln, int batch, Resident& res) {
   const bool fast = setup_weights<kRows, kWR, kHoist>(p, sm, ln, res);
   setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast);
@@ -1058,8 +1127,8 @@ __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int blo
 
 // kReset: also forget the pending harmonic sum and clear Shared::fk (a fresh
 // launch); without it only the parameters the NEXT sums are computed from change.
-template <int kRows, int kWR, bool kReset = true>
-__device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& res,
+template <int kRows, int kWR, bool kReset = true, bool kWide = false>
+__device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide>& sm, Resident& res,
                                               const SampleSetup& s) {
   constexpr int kThreads = kRows / kWR * 64;
   res.frc_a = s.a; res.frc_omega = s.omega; res.frc_phi = s.phi;
@@ -1073,8 +1142,8 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR>& sm, Resident& 
   }
 }
 
-template <int kRows, int kWR>
-__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR>& sm,
+template <int kRows, int kWR, bool kWide>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               int block, int batch, Resident& res,
                                               bool fast) {
   apply_samples<kRows, kWR>(sm, res, fetch_samples<kRows, kWR>(p, block, batch, fast));
@@ -1084,10 +1153,10 @@ __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, 
 // Kernel 1: one fused RK substep (also: plain time derivative, derivative and
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
-template <int kRows, int kWR, int kEq = -1>
+template <int kRows, int kWR, int kEq = -1, bool kWide = false>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams p,
                                                                       SubstepArgs a) {
-  __shared__ Shared<kRows, kWR> sm;
+  __shared__ Shared<kRows, kWR, kWide> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
@@ -1181,10 +1250,10 @@ constexpr bool kTraceByDefault = true;
 constexpr bool kTraceByDefault = false;
 #endif
 template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1,
-          bool kTrace = (kEq < 0) && kTraceByDefault>
+          bool kTrace = (kEq < 0) && kTraceByDefault, bool kWide = false>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
                                                                         IntegrateArgs a) {
-  __shared__ Shared<kRows, kWR> sm;
+  __shared__ Shared<kRows, kWR, kWide> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);

@@ -29,19 +29,63 @@ ALL_EQUATIONS = [
 ]
 
 
+_F64_ACTIVATIONS = {
+    'relu': lambda x: np.maximum(x, 0.0), 'relu6': lambda x: np.clip(x, 0.0, 6.0),
+    'tanh': np.tanh, 'softplus': lambda x: np.logaddexp(x, 0.0),
+    'elu': lambda x: np.where(x > 0, x, np.expm1(x)),
+}
+
+
+def _f64_coefficients(spec, y0):
+  """predict_coefficients (model.py:420-513) evaluated ENTIRELY in float64 from
+  the float32 weights and tables: the conv tower (layers.py:39-137 alignment:
+  tap k reads x + k - ceil((K - 1) / 2)), the projection / direct head, the
+  optional mean subtraction.  The distance of the float32 oracle from this is
+  the float32 rounding noise of the formulas themselves."""
+  net = (np.asarray(y0, np.float64) / np.float64(np.float32(spec['standard_deviation'])))[..., None]
+  act = _F64_ACTIVATIONS[spec['nonlinearity']]
+  layers = list(zip(spec['conv_kernels'], spec['conv_biases']))
+  for index, (kernel, bias) in enumerate(layers):
+    taps = kernel.shape[0]
+    left = -(-(taps - 1) // 2)
+    out = np.zeros(net.shape[:2] + (kernel.shape[2],))
+    for k in range(taps):
+      out += np.einsum('bxc,cf->bxf', np.roll(net, left - k, axis=1),
+                       kernel[k].astype(np.float64))
+    out += bias.astype(np.float64)
+    net = act(out) if index < len(layers) - 1 else out
+  num_d, size = len(spec['derivative_orders']), spec['stencil_size']
+  if not spec['polynomial_accuracy_order']:
+    coeff = net.reshape(net.shape[:2] + (num_d, size))
+    if spec.get('ensure_unbiased_coefficients', False):
+      coeff = coeff - coeff.mean(axis=-1, keepdims=True)
+    return coeff
+  out, start = [], 0
+  for nullspace, bias in zip(spec['nullspaces'], spec['biases']):
+    stop = start + nullspace.shape[0]
+    out.append(np.float32(bias).astype(np.float64) + net[..., start:stop] @
+               np.float32(nullspace).astype(np.float64))
+    start = stop
+  return np.stack(out, axis=-2)
+
+
 def _f64_derivatives(spec, y0):
   """Stencil apply in float64 from the float32 coefficients; None for heads
   that do not predict coefficients."""
-  if spec.get('model_target', 'coefficients') != 'coefficients':
+  if spec.get('model_target', 'coefficients') != 'coefficients' or spec['num_layers'] == 0:
     return None
-  coeff = oracle.predict_coefficients(y0, spec).astype(np.float64)
+  coeff = _f64_coefficients(spec, y0)
   patches = oracle.extract_patches(y0.astype(np.float64), coeff.shape[3])
   return np.einsum('bxdi,bxi->bxd', coeff, patches)
 
 
 def _measured_tol(spec, y0, t, forcing, want):
   """max(1e-5, 4 x float32 noise floor of the oracle itself on these inputs)."""
-  truth = _f64_truth(spec, y0)
+  derivs = _f64_derivatives(spec, y0)
+  if derivs is None:
+    return TOL, 0.0
+  truth = oracle.equation_of_motion(spec['equation'], y0.astype(np.float64), derivs,
+                                    spec['eta'], spec['dx'])
   if spec.get('forced', False) and forcing is not None:
     truth = truth + oracle.forcing_f64(t, forcing, spec['num_points'],
                                        spec['resample_factor'], spec['period'],
@@ -164,19 +208,28 @@ def test_direct_heads_on_mfma(equation, overrides):
   assert rel_err(got, want) < tol
 
 
-def test_accuracy_order_zero_with_three_derivatives_stays_generic():
+def test_accuracy_order_zero_with_three_derivatives_runs_on_the_wide_kernels():
+  """3 x 6 = 18 direct coefficient channels (training_test.py:57): beyond the
+  default MFMA kernels' 16, carried by the wide flavour; same numbers as the
+  generic kernel."""
   model = make_model('ks', True, num_points=64, polynomial_accuracy_order=0)
-  assert model.kernel_name == 'generic'       # 3 x 6 = 18 coefficient channels > 16
+  assert model.kernel_name == 'mfma_f32_r64'
+  y0 = random_phase_ic(model.equation, 3)
+  a = model.time_derivative(y0, 0.0).cpu().numpy()
+  model.set_kernel('generic')
+  b = model.time_derivative(y0, 0.0).cpu().numpy()
+  assert model.kernel_name == 'generic' and rel_err(a, b) < TOL
 
 
 @pytest.mark.parametrize('overrides', [
     dict(num_layers=1), dict(filter_size=16), dict(kernel_size=3),
-    dict(kernel_size=4), dict(coefficient_grid_min_size=9),
+    dict(kernel_size=4), dict(coefficient_grid_min_size=13),
     dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
-  """Configurations enumerated by training_test.py:54-83 that the MFMA path
-  does not cover run on the generic kernel (never on the CPU)."""
+  """Configurations the MFMA path does not cover (other filter / kernel sizes,
+  one-layer nets, stencils wider than 12) run on the generic kernel (never on
+  the CPU)."""
   conservative = not overrides.get('ensure_unbiased_coefficients', False)
   model = make_model('burgers', conservative, num_points=64, **overrides)
   if overrides.get('num_layers', 3) != 0:
@@ -353,3 +406,77 @@ def test_standard_deviation_without_exact_division_shortcut():
     traj = model.integrate_fixed(y0, 20, dt=2.5e-5, save_every=20).cpu().numpy()
     want = oracle.integrate_fixed(spec, oracle.SCHEME_MIDPOINT, 0.0, 2.5e-5, 20, 20, y0)
     assert rel_err(traj, want) < TOL
+
+
+# ---------------------------------------------------------------------------
+# The wide flavour of the run-time-parameterised MFMA kernels: stencils up to 12
+# points, up to 24 output channels (training_test.py:56-57: ks with
+# coefficient_grid_min_size = 9; ks with polynomial_accuracy_order = 0)
+# ---------------------------------------------------------------------------
+WIDE_MODELS = [
+    ('ks', True, dict(coefficient_grid_min_size=9)),            # G = 10, D = 3, 23 channels
+    ('ks', False, dict(coefficient_grid_min_size=9)),           # G = 9 or 11 (centred)
+    ('ks', True, dict(polynomial_accuracy_order=0)),            # 3 x 6 = 18 direct channels
+    ('ks', False, dict(polynomial_accuracy_order=0, ensure_unbiased_coefficients=True)),
+    ('burgers', True, dict(coefficient_grid_min_size=9)),       # G = 10, 17 channels, forced
+    ('kdv', False, dict(coefficient_grid_min_size=11, nonlinearity='tanh', num_layers=4)),
+]
+
+
+@pytest.mark.parametrize('equation,conservative,overrides', WIDE_MODELS)
+@pytest.mark.parametrize('num_points', [64, 32, 256, 100])
+def test_wide_models_on_mfma(equation, conservative, overrides, num_points):
+  model = make_model(equation, conservative, num_points=num_points,
+                     resample_factor=2, **overrides)
+  assert model.kernel_name.startswith('mfma_f32'), model.kernel_name
+  batch = 5
+  y0 = random_phase_ic(model.equation, batch)
+  forcing = batch_forcing(batch, seed0=7)
+  model.set_forcing(forcing)
+  err = _check_all_views(model, y0, 0.6, forcing, None)
+  print(equation, conservative, overrides, num_points, model.kernel_name, 'G',
+        model.stencil_size, 'rel err {:.1e}'.format(err))
+
+
+def test_wide_models_trajectories_all_launch_shapes():
+  """Persistent, one launch per substep, float64 state and the adaptive
+  controller on a wide model, against the oracle."""
+  model = make_model('ks', True, num_points=64, resample_factor=2,
+                     coefficient_grid_min_size=9)
+  spec = model.spec()
+  y0 = random_phase_ic(model.equation, 6)
+  dt = 2.5e-5
+  want = oracle.integrate_fixed(spec, oracle.SCHEME_MIDPOINT, 0.0, dt, 40, 20, y0)
+  got = model.integrate_fixed(y0, 40, dt=dt, save_every=20).cpu().numpy()
+  sub = model.integrate_fixed(y0, 40, dt=dt, save_every=20,
+                              launch_mode='per_substep').cpu().numpy()
+  f64 = model.integrate_fixed(y0, 40, dt=dt, save_every=20,
+                              state_dtype='float64').cpu().numpy()
+  assert rel_err(got, want) < TOL and rel_err(f64, want) < TOL
+  np.testing.assert_array_equal(got, sub)
+  times = np.linspace(0, 0.05, 3)
+  y, nfev, status = model.integrate_adaptive(y0.astype(np.float64), times)
+  for b in (0, 5):
+    ref, ref_nfev = oracle.odeint_rk23(spec, y0[b], times)
+    assert int(nfev[b]) == ref_nfev and rel_err(y[:, b].cpu().numpy(), ref) < TOL
+
+
+def test_output_channel_groups_issued_in_pairs():
+  """Run-time kernels issue only the live channel groups (two by two, a lone
+  last one): 8 channels (KdV, unfolded), 9 (Burgers, pair + lone), 1 (the
+  time-derivative head), 16 (Godunov KS, two pairs) -- all against the oracle."""
+  cases = [('kdv', False, False, dict(nonlinearity='relu6')),
+           ('burgers', True, False, dict(nonlinearity='relu6')),
+           ('burgers', False, False, dict(model_target='time_derivative', nonlinearity='elu')),
+           ('ks', True, True, dict(nonlinearity='relu6'))]
+  for equation, conservative, flux, overrides in cases:
+    model = make_model(equation, conservative, flux, num_points=64, **overrides)
+    assert model.kernel_name == 'mfma_f32_r64'
+    y0 = random_phase_ic(model.equation, 4)
+    forcing = batch_forcing(4)
+    model.set_forcing(forcing)
+    _check_all_views(model, y0, 0.2, forcing, None)
+    traj = model.integrate_fixed(y0, 10, dt=1e-5, save_every=10).cpu().numpy()
+    want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, 1e-5, 10, 10, y0,
+                                  forcing=forcing)
+    assert rel_err(traj, want) < TOL, (equation, overrides)
