@@ -102,6 +102,9 @@ def parse_args(argv=None):
   ap.add_argument('--non-conservative', action='store_true')
   ap.add_argument('--baseline-stencils', action='store_true',
                   help='fixed polynomial stencils instead of the conv net')
+  ap.add_argument('--hparams', default='{}',
+                  help='JSON overrides of the model hyper-parameters (create_hparams), e.g. '
+                       '\'{"coefficient_grid_min_size": 9}\' or \'{"nonlinearity": "tanh"}\'')
   ap.add_argument('--kernel', default='auto',
                   choices=['auto', 'mfma', 'mfma64', 'mfma64w32', 'mfma256', 'generic'])
   ap.add_argument('--preheat-ms', type=float, default=300.0,
@@ -141,7 +144,8 @@ def build_workload(args, rank, batch, unique=None):
   hp = ddd1d_amd.create_hparams(
       args.equation, conservative=not args.non_conservative,
       resample_factor=rf,
-      equation_kwargs=json.dumps({'num_points': args.num_points * rf}))
+      equation_kwargs=json.dumps({'num_points': args.num_points * rf}),
+      **json.loads(getattr(args, 'hparams', '{}') or '{}'))
   _, eq = equations.from_hparams(hp, random_seed=0)
   if args.baseline_stencils:
     model = model_lib.BaselineModel(eq, accuracy_order=1)
@@ -758,7 +762,7 @@ def main():
             'parallelism': 'ensemble-shard x{}'.format(world),
             'backend': args.backend if world > 1 else None,
             'finite': m['finite'],
-            'debug_options': args.debug_option,
+            'debug_options': args.debug_option, 'hparams': json.loads(args.hparams or '{}'),
             'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,
             'timed_wall_ms': m['wall'] * 1e3,
         },

@@ -403,15 +403,15 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
         }
       return packed4;
     };
-    // Run-time-parameterised kernels: the live channel groups are issued two by
-    // two (rhs_mfma.h: a pair = two interleaved accumulator chains at 8.1 cycles
-    // per MFMA, a lone last group 13.2).  Folding the projection trades the
+    // Run-time-parameterised kernels: only the live channel groups are issued,
+    // as interleaved accumulator chains (rhs_mfma.h: two or three chains run at
+    // 8.1 cycles per MFMA, a lone group at 13.2).  Folding the projection trades the
     // epilogue's ~C_out x G FMAs (~2.5 units of 161 MFMA slots) for D x G
     // instead of C_out channels: fold only where the matrix work does not grow
     // by more than that (the same outcome as rhs_mfma.h: spec_folded for the six
     // default models, so the two kernel families stay bit-identical).
     // polynomial_accuracy_order = 0 has nothing to project.
-    const auto issue_cost = [](int groups) { return 16.2 * (groups / 2) + 13.2 * (groups % 2); };
+    const auto issue_cost = [](int groups) { return groups == 1 ? 13.2 : 8.1 * groups; };
     const int groups_rt_plain = (dp.C_out + 3) / 4;
     const int groups_rt_folded = (dp.D * dp.G + 3) / 4;
     const bool fold_rt = can_fold && (direct_coeffs || issue_cost(groups_rt_folded) <=
@@ -422,21 +422,28 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
       const float* w = fold_rt ? wf.data() : w_nat;
       const float* b = fold_rt ? bf.data() : b_nat;
       const int cout_n = fold_rt ? 16 : dp.C_out;
-      const int pairs = (m->dp.rt_groups + 1) / 2, pair_rows = ddd::mfma::fin4_regs(2);
-      std::vector<float> packed((size_t)pairs * pair_rows * 64, 0.0f);
-      for (int gp = 0; gp < pairs; ++gp) {
-        const int ng = std::min(2, m->dp.rt_groups - 2 * gp);   // 2, or a lone last group
+      // layout: the head chunk (rt_head_groups: 0, 1 or 3 groups, fin4_regs(head)
+      // rows), then the pairs (fin4_regs(2) rows each); + slack so that the
+      // kernels' fixed-size first fetch (fin4_regs(3) rows) stays inside
+      const int groups = m->dp.rt_groups, head = ddd::mfma::rt_head_groups(groups);
+      const int pair_rows = ddd::mfma::fin4_regs(2), head_rows = ddd::mfma::fin4_regs(head);
+      const int total_rows = head_rows + (groups - head) / 2 * pair_rows + ddd::mfma::fin4_regs(3);
+      std::vector<float> packed((size_t)total_rows * 64, 0.0f);
+      const auto pack_chunk = [&](int row0, int first_group, int ng) {
         for (int k = 0; k < ddd::mfma::kFin4K; ++k)
           for (int gi = 0; gi < ng; ++gi) {
             const int q = k * ng + gi;
             for (int r = 0; r < 4; ++r) {
-              const int ch = 4 * (2 * gp + gi) + r;
+              const int ch = 4 * (first_group + gi) + r;
               if (ch >= cout_n) continue;
-              packed[((size_t)gp * pair_rows + q / 16) * 64 + 4 * (q % 16) + r] =
+              packed[((size_t)row0 + q / 16) * 64 + 4 * (q % 16) + r] =
                   k < 160 ? w[(size_t)k * cout_n + ch] : b[ch];
             }
           }
-      }
+      };
+      if (head > 0) pack_chunk(0, 0, head);
+      for (int g0 = head; g0 < groups; g0 += 2)
+        pack_chunk(head_rows + (g0 - head) / 2 * pair_rows, g0, 2);
       int rc2 = upload(packed, &m->d_w_final4_rt);
       if (rc2) return rc2;
       m->dp.w_final4_rt = m->d_w_final4_rt;

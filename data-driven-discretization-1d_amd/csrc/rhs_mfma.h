@@ -138,6 +138,12 @@ __host__ __device__ constexpr int spec_fin_channels(int eq) {
 }
 __host__ __device__ constexpr int spec_fin_groups(int eq) { return (spec_fin_channels(eq) + 3) / 4; }
 __host__ __device__ constexpr int fin4_regs(int groups) { return (kFin4K * groups + 15) / 16; }
+// Run-time kernels issue their live channel groups as a head chunk followed by
+// pairs: an even count has no head (0), a single group is its own head (1), any
+// other odd count starts with three interleaved groups.
+__host__ __device__ constexpr int rt_head_groups(int groups) {
+  return groups % 2 == 0 ? 0 : groups == 1 ? 1 : 3;
+}
 
 struct Lane {
   int row;       // row inside the workgroup this lane owns in VALU phases
@@ -630,8 +636,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   constexpr int kGW = flavour_stencil(kWide);    // stencil columns carried
   constexpr int kCh = flavour_channels(kWide);   // output channels carried
   static_assert(!(kSpec && kWide), "the per-equation kernels have no wide flavour");
-  // specialised one-wave integrators keep loop invariants in registers
-  constexpr bool kKeepRows = kWR == 64 && kHoist && kEq >= 0;
+  // 64-row-wavefront integrators with one hidden layer keep the loop-invariant
+  // LDS offsets / permute addresses / patch indices in registers (kKeepOffsets);
+  // the per-equation ones also the output layer's weights and the grid point's
+  // cos / sin table (kKeepRows)
+  constexpr bool kKeepOffsets = kWR == 64 && kHoist;
+  constexpr bool kKeepRows = kKeepOffsets && kEq >= 0;
+  constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
   const int tid = opaque((int)threadIdx.x);
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
   if (ln.owner) sm.u[ln.row] = u;
@@ -639,7 +650,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][kKW];
   if (!fixed) {
-    if (kKeepRows) {
+    if (kKeepOffsets) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -684,7 +695,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   if (!kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGW; ++g)
-      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g < kGMax ? g : 0]
+      pch[g] = (g < nG) ? sm.u[kKeepPatch ? res.pch_idx[g < kGMax ? g : 0]
                                : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
                                       : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
@@ -695,35 +706,41 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   if (!fixed) {
     DDD_STAMP(1);
     if (!(ablate & 16))
-      input_layer<kWR, kOneWave, kKeepRows>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows, act,
-                                            res.in_perm);
+      input_layer<kWR, kOneWave, kKeepOffsets>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows,
+                                               act, res.in_perm);
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
+    // output layer weights that are not resident: requested now, an L2 latency
+    // ahead of the hidden layer's ~10 k cycles of MFMAs
+    // (run-time kernels: the first chunk, up to three groups)
+    constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs(3);
+    float wf4[kFirstRows];
+    if (!kKeepRows) {
+      const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
+#pragma unroll
+      for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
+    }
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
       __syncthreads();
-      hidden_layer<kWR, kKeepRows>(p, ln, in, out, res.hid, hid_rows, act);
+      hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act);
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
     {
       // output layer: weights resident (specialised one-wave integrators) or
-      // re-fetched from L2 here, in flight across the forcing sums below
-      float wf4[fin4_regs(kNG)];
+      // fetched from L2 above
       int off4[kKW];
       if (kKeepRows) {
 #pragma unroll
-        for (int s2 = 0; s2 < fin4_regs(kNG); ++s2) wf4[s2] = res.w_fin4[s2];
+        for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = res.w_fin4[s2];
+      }
+      if (kKeepOffsets) {
 #pragma unroll
         for (int k = 0; k < kKW; ++k) off4[k] = res.fin4_off[k];
       } else {
-        // (run-time kernels: the first pair's weights; the next pairs' are
-        // fetched while the previous pair's MFMAs run)
-        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
-#pragma unroll
-        for (int s2 = 0; s2 < fin4_regs(kNG); ++s2) wf4[s2] = wsrc[s2 * 64];
         int rows5[kKW];
         tap_rows<kRows == 64>(ln, ln.row, p.N, rows5);
 #pragma unroll
@@ -752,42 +769,74 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
 #pragma unroll
           for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc4[g4][r4];
       } else if constexpr (!kSpec) {
-        // live groups two by two: a pair is two interleaved accumulator chains
-        // (8.1 cycles per MFMA; a lone chain runs at 13.2, still cheaper than a
-        // padded pair), so a net with 8 channels issues half the matrix work of
-        // one with 16 instead of the same.  Wave-uniform branches.
+        // Only the live groups are issued, as interleaved accumulator chains (two
+        // or more chains run at 8.1 cycles per MFMA, a lone one at 13.2): a head
+        // chunk of 3 groups when the count is odd (1 when there is only one),
+        // then pairs -- a net with 8 channels issues half the matrix work of one
+        // with 16 instead of the same.  Wave-uniform branches; every chunk's
+        // weights are fetched while the previous chunk's MFMAs run.
         constexpr int kPairRows = fin4_regs(2);
-#pragma unroll
-        for (int gp = 0; gp < kCh / 8; ++gp) {
-          if (2 * gp >= p.rt_groups || (ablate & 4)) break;
-          const bool lone = 2 * gp + 1 >= p.rt_groups;
+        const int head = rt_head_groups(p.rt_groups);
+        int done = 0;   // groups issued so far
+        if (!(ablate & 4)) {
           float wnext[kPairRows];
-          if (2 * gp + 2 < p.rt_groups) {   // the following pair's (or lone group's) weights
-            const float* __restrict__ wn =
-                p.w_final4_rt + (size_t)(gp + 1) * kPairRows * 64 + opaque(ln.lane);
+          const auto fetch_pair = [&](int first_group) {
+            const float* __restrict__ wn = p.w_final4_rt +
+                (size_t)(fin4_regs(head) + (first_group - head) / 2 * kPairRows) * 64 +
+                opaque(ln.lane);
 #pragma unroll
             for (int s2 = 0; s2 < kPairRows; ++s2) wnext[s2] = wn[s2 * 64];
-          }
-          if (!lone) {
-            f32x4 acc2[2];
-            final_layer4<2>(in, wf4, off4, acc2);
+          };
+          if (head > 0 && head < p.rt_groups) fetch_pair(head);   // (head 0: pair 0 is in wf4)
+          if (head == 3) {
+            f32x4 acc3[3];
+            final_layer4<3>(in, wf4, off4, acc3);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-              net[8 * gp + r4] = acc2[0][r4];
-              net[8 * gp + 4 + r4] = acc2[1][r4];
-            }
-          } else {
+            for (int g4 = 0; g4 < 3; ++g4)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc3[g4][r4];
+          } else if (head == 1) {
             float w1[fin4_regs(1)];
 #pragma unroll
             for (int s2 = 0; s2 < fin4_regs(1); ++s2) w1[s2] = wf4[s2];
             f32x4 acc1[1];
             final_layer4<1>(in, w1, off4, acc1);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) net[8 * gp + r4] = acc1[0][r4];
+            for (int r4 = 0; r4 < 4; ++r4) net[r4] = acc1[0][r4];
           }
-          if (2 * gp + 2 < p.rt_groups) {
+          done = head;
+          // pairs: group index 2 j (head 0) or 2 j + 1 (odd head): compile-time slots
 #pragma unroll
-            for (int s2 = 0; s2 < kPairRows; ++s2) wf4[s2] = wnext[s2];
+          for (int j = 0; j < kCh / 8; ++j) {
+            if (done >= p.rt_groups) break;
+            float w2[kPairRows];
+#pragma unroll
+            for (int s2 = 0; s2 < kPairRows; ++s2) w2[s2] = (head == 0 && j == 0) ? wf4[s2] : wnext[s2];
+            if (done + 2 < p.rt_groups) fetch_pair(done + 2);
+            f32x4 acc2[2];
+            final_layer4<2>(in, w2, off4, acc2);
+            if (head == 0) {
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                net[8 * j + r4] = acc2[0][r4];
+                net[8 * j + 4 + r4] = acc2[1][r4];
+              }
+            } else if (8 * j + 12 <= kCh) {   // odd head: groups 2 j + head, 2 j + head + 1
+              if (head == 1) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  net[8 * j + 4 + r4] = acc2[0][r4];
+                  net[8 * j + 8 + r4] = acc2[1][r4];
+                }
+              } else if (8 * j + 20 <= kCh) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                  net[8 * j + 12 + r4] = acc2[0][r4];
+                  net[8 * j + 16 + r4] = acc2[1][r4];
+                }
+              }
+            }
+            done += 2;
           }
         }
       }
@@ -810,7 +859,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // the epilogue, consumed by its last statement
   float4 trig4[kTrigMax / 4];
   if (forced && fast_forcing) {
-    if (kKeepRows) {
+    if (kKeepOffsets) {
       // resident for the launch: lane == grid point never changes
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = res.trig[i];
@@ -830,7 +879,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   if (kOneWave) {
 #pragma unroll
     for (int g = 0; g < kGW; ++g)
-      pch[g] = (g < nG) ? sm.u[kKeepRows ? res.pch_idx[g < kGMax ? g : 0]
+      pch[g] = (g < nG) ? sm.u[kKeepPatch ? res.pch_idx[g < kGMax ? g : 0]
                                : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
                                       : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
@@ -969,7 +1018,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
-        if (i == 2 && trig_lds && !kKeepRows) break;   // entries 8..11 are zero padding
+        if (i == 2 && trig_lds && !kKeepOffsets) break;   // entries 8..11 are zero padding
         const float4 f = fk4[i];
         total = fmaf(f.x, trig4[i].x, total);
         total = fmaf(f.y, trig4[i].y, total);
@@ -1028,9 +1077,11 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     // loop invariants the specialised one-wave integrators keep resident
     // (kHoist: the persistent kernels; a single fused substep has no loop)
     if (kHoist && kWR == 64) {
+      if (p.w_final4 != nullptr) {   // (dead in the run-time kernels, null for wide models)
 #pragma unroll
-      for (int s = 0; s < fin4_regs(4); ++s)   // buffer holds fin4_regs(4) rows (zero padded)
-        res.w_fin4[s] = p.w_final4[s * 64 + ln.lane];
+        for (int s = 0; s < fin4_regs(4); ++s)   // buffer holds fin4_regs(4) rows (zero padded)
+          res.w_fin4[s] = p.w_final4[s * 64 + ln.lane];
+      }
       {
         int rows[kKW];
         tap_rows<kRows == 64>(ln, ln.row, p.N, rows);

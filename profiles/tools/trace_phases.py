@@ -3,6 +3,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import ddd1d_amd
 from ddd1d_amd import equations, model as model_lib
 ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
+if 'no_spec' in sys.argv:   # trace the run-time-parameterised kernel instead of the per-equation one
+    ddd1d_amd._lib.debug_set_option('no_spec', 1)
+    sys.argv.remove('no_spec')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}))
 _, eq = equations.from_hparams(hp)
