@@ -95,7 +95,7 @@ def parse_args(argv=None):
   ap.add_argument('--scheme', default='midpoint',
                   choices=['euler', 'midpoint', 'bs3', 'rk4'])
   ap.add_argument('--launch-mode', default='persistent',
-                  choices=['persistent', 'per_substep'])
+                  choices=['persistent', 'per_substep', 'per_step'])
   ap.add_argument('--state-dtype', default='float32', choices=['float32', 'float64'],
                   help='float64: state and RK update in f64, right-hand side in f32 '
                        '(the reference SciPy path, integrate.py:154)')
@@ -458,11 +458,13 @@ def summarize(args, eq, model, m, world, n, batch, stages):
   steps_timed = args.steps * m['reps']
   total_points = batch * n * steps_timed * world
   fma = model.fma_per_point
-  launches_per_job = 1 if args.launch_mode == 'persistent' else args.steps * stages
+  # (launches per sample: large ensembles run as two half-ensemble launches side by side)
+  launches_per_job = (1 if args.launch_mode == 'persistent' else
+                      args.steps if args.launch_mode == 'per_step' else args.steps * stages)
   launches = launches_per_job * m['reps']
   flops_per_launch = 2.0 * fma * batch * n * stages * args.steps / launches_per_job
   state_bytes = 8.0 if args.state_dtype == 'float32' else 16.0   # in + out per point
-  bytes_per_launch = (state_bytes * batch * n if args.launch_mode == 'persistent' else
+  bytes_per_launch = (state_bytes * batch * n if args.launch_mode != 'per_substep' else
                       (20.0 if args.scheme == 'midpoint' else 8.0 * stages)
                       * batch * n / stages)
   launch_s = m['kernel_ms'] * 1e-3 / launches

@@ -185,6 +185,11 @@ struct ddd_model {
   double* d_kernels = nullptr;
   double* d_scratch64 = nullptr;
   size_t scratch64_doubles = 0;
+  // per-substep launch mode: the ensemble is advanced as two half-ensembles on two
+  // internal streams, so that one half's launch boundary overlaps the other's
+  // steady state (ddd_integrate_fixed)
+  hipStream_t aux_stream[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // output times of ddd_integrate_adaptive_f64
   double* d_times = nullptr;
   size_t times_capacity = 0;
@@ -623,7 +628,11 @@ bool use_stream_kernel(const ddd_model* m, const ddd::SubstepArgs& a) {
          aligned16(a.acc_in) && aligned16(a.acc_out);
 }
 
-int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
+// sample0: index of a.y_in's first sample in the model's per-sample tables (a
+// half-ensemble launch); grid_share: this launch may occupy 1 / grid_share of
+// the machine-sized grid (it runs next to grid_share - 1 others).
+int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, int sample0 = 0,
+                   int grid_share = 1) {
   if (a.batch == 0) return DDD_OK;
   m->last_batch = a.batch;
   if (use_stream_kernel(m, a)) {
@@ -639,6 +648,11 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
   m->last_launch_streamed = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
+    ddd::DevParams dp = m->dp;
+    if (sample0 != 0 && dp.forced) {   // per-sample forcing rows of this slab
+      dp.frc += (size_t)sample0 * dp.P;
+      dp.runs += (size_t)sample0 * 8;
+    }
     const MfmaGeometry geo = mfma_geometry(m, a.batch);
     const int spg = geo.rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
@@ -647,9 +661,10 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
                        ? spec_equation(m, geo.rows) : -1;
     // specialised models: machine-sized grid, weights resident per wavefront,
     // each group walks over several row groups (substep_multi_kernel)
-    const int grid = std::min(blocks, geo.rows == 64 ? 2 * device_simds() : device_simds() / 2);
+    const int grid = std::min(blocks, (geo.rows == 64 ? 2 * device_simds() : device_simds() / 2) /
+                                          std::max(grid_share, 1));
 #define DDD_SUBSTEP_CASE(EQ) \
-    case EQ: ddd::launch::substep_spec<EQ>(geo.rows, m->dp, a, blocks, grid, stream); break;
+    case EQ: ddd::launch::substep_spec<EQ>(geo.rows, dp, a, blocks, grid, stream); break;
     switch (eq) {
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS)
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS_CONS)
@@ -659,10 +674,10 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) 
       DDD_SUBSTEP_CASE(ddd::EQ_KS_CONS)
       default:
         if (m->wide) {
-          if (geo.rows == 64) ddd::launch::substep_wide_unit<64>(m->dp, a, blocks, stream);
-          else ddd::launch::substep_wide_unit<256>(m->dp, a, blocks, stream);
+          if (geo.rows == 64) ddd::launch::substep_wide_unit<64>(dp, a, blocks, stream);
+          else ddd::launch::substep_wide_unit<256>(dp, a, blocks, stream);
         } else {
-          ddd::launch::substep_runtime(geo.rows, geo.wave_rows, m->dp, a, blocks, stream);
+          ddd::launch::substep_runtime(geo.rows, geo.wave_rows, dp, a, blocks, stream);
         }
     }
 #undef DDD_SUBSTEP_CASE
@@ -1015,6 +1030,11 @@ int ddd_model_destroy(ddd_model* m) {
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   free_dev(m->d_times);
+  for (int i = 0; i < 2; ++i) {
+    if (m->aux_stream[i] != nullptr) (void)hipStreamDestroy(m->aux_stream[i]);
+    if (m->ev_join[i] != nullptr) (void)hipEventDestroy(m->ev_join[i]);
+  }
+  if (m->ev_fork != nullptr) (void)hipEventDestroy(m->ev_fork);
   if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
   if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
   delete m;
@@ -1179,7 +1199,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     a.y0 = y0; a.y_out = y_out; a.batch = batch;
     return launch_integrate<float>(m, a, stream);
   }
-  if (launch_mode != DDD_LAUNCH_PER_SUBSTEP)
+  if (launch_mode != DDD_LAUNCH_PER_SUBSTEP && launch_mode != DDD_LAUNCH_PER_STEP)
     return fail(DDD_ERR_INVALID_ARGUMENT, "unknown launch_mode %d", launch_mode);
   if (batch == 0 || n_steps == 0) return DDD_OK;
 
@@ -1191,33 +1211,128 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   float* pong = m->d_scratch + elems;
   float* ystage = m->d_scratch + 2 * elems;
   const float h = (float)dt;
+
+  // Large ensembles on the per-equation MFMA kernels are advanced as TWO
+  // half-ensembles (contiguous sample slabs, independent of each other) on two
+  // internal streams, each launch sized to half the machine and the second
+  // chain started half a substep late: while one half is at a kernel boundary
+  // (drain, dispatch, 29 KB of weights per wavefront before the first MFMA) the
+  // other half's wavefronts have the matrix pipes to themselves, which a single
+  // wavefront per SIMD nearly saturates.  Still one fused launch per substep for
+  // every sample; results are bit-identical (same kernel, same arithmetic).
+  int halves = 1;
+  int half_batch[2] = {batch, 0};
+  int step_eq = -1;   // per-equation kernel for DDD_LAUNCH_PER_STEP
+  if (m->kernel == DDD_KERNEL_MFMA && !m->explicit_kernel && !g_debug.no_spec) {
+    const MfmaGeometry geo = mfma_geometry(m, batch);
+    const int spg = geo.rows / m->dp.N;
+    const int groups = (batch + spg - 1) / spg;
+    const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
+    if (geo.wave_rows == 64 && launch_mode == DDD_LAUNCH_PER_STEP)
+      step_eq = spec_equation(m, geo.rows);
+    if (geo.wave_rows == 64 && spec_equation(m, geo.rows) >= 0 && groups >= 2 * capacity) {
+      halves = 2;
+      half_batch[0] = ((groups + 1) / 2) * spg;   // whole workgroups
+      half_batch[1] = batch - half_batch[0];
+    }
+  }
+  hipStream_t lanes[2] = {stream, stream};
+  if (halves == 2) {
+    for (int i = 0; i < 2; ++i) {
+      if (m->aux_stream[i] == nullptr)
+        DDD_HIP(hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking));
+      if (m->ev_join[i] == nullptr)
+        DDD_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+      lanes[i] = m->aux_stream[i];
+    }
+    if (m->ev_fork == nullptr)
+      DDD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    DDD_HIP(hipEventRecord(m->ev_fork, stream));
+    for (int i = 0; i < 2; ++i) DDD_HIP(hipStreamWaitEvent(lanes[i], m->ev_fork, 0));
+    // the second chain starts half a substep late (estimate: ~6 us per launch +
+    // ~14.5 us per row group a wavefront walks over; 100 ticks of s_memrealtime = 1 us)
+    const MfmaGeometry geo = mfma_geometry(m, batch);
+    const int spg = geo.rows / m->dp.N;
+    const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
+    const int passes = ((half_batch[0] + spg - 1) / spg + capacity / 2 - 1) / (capacity / 2);
+    const double est_us = 6.0 + 14.5 * passes * (geo.rows == 64 ? 1.0 : 4.0) *
+                                    (step_eq >= 0 ? tab.stages : 1);
+    hipLaunchKernelGGL(ddd::ops::delay_kernel, dim3(1), dim3(64), 0, lanes[1],
+                       (unsigned)(50.0 * est_us));
+    DDD_HIP(hipGetLastError());
+  }
+  const size_t half_off[2] = {0, (size_t)half_batch[0] * m->dp.N};
   const float* y = y0;
   size_t snap = 0;
   for (int step = 0; step < n_steps; ++step) {
     const double t = t0 + (double)step * dt;
     const bool saving = (step + 1) % save_every == 0;
     float* ynew = saving ? y_out + snap * elems : (y == ping ? pong : ping);
+    if (step_eq >= 0) {
+      // all stages in one launch per half-ensemble (step_multi_kernel)
+      m->dp.dpp_rol = dpp_wave_rol_ok();
+      const MfmaGeometry geo = mfma_geometry(m, batch);
+      const int spg = geo.rows / m->dp.N;
+      const int capacity = (geo.rows == 64 ? 2 * device_simds() : device_simds() / 2) / halves;
+      for (int hf = 0; hf < halves; ++hf) {
+        ddd::DevParams dp = m->dp;
+        if (hf == 1 && dp.forced) {
+          dp.frc += (size_t)half_batch[0] * dp.P;
+          dp.runs += (size_t)half_batch[0] * 8;
+        }
+        ddd::StepArgs sa{};
+        sa.t = t; sa.dt = dt; sa.tab = tab;
+        sa.y_in = y + half_off[hf]; sa.y_out = ynew + half_off[hf]; sa.batch = half_batch[hf];
+        const int groups = (half_batch[hf] + spg - 1) / spg;
+        const int grid = std::min(groups, capacity);
+        switch (step_eq) {
+#define DDD_STEP_CASE(EQ) \
+          case EQ: ddd::launch::step_spec<EQ>(geo.rows, dp, sa, groups, grid, lanes[hf]); break;
+          DDD_STEP_CASE(ddd::EQ_BURGERS) DDD_STEP_CASE(ddd::EQ_BURGERS_CONS)
+          DDD_STEP_CASE(ddd::EQ_KDV) DDD_STEP_CASE(ddd::EQ_KDV_CONS)
+          DDD_STEP_CASE(ddd::EQ_KS) DDD_STEP_CASE(ddd::EQ_KS_CONS)
+#undef DDD_STEP_CASE
+          default: break;
+        }
+      }
+      DDD_HIP(hipGetLastError());
+      m->last_launch_streamed = false;
+      y = ynew;
+      if (saving) ++snap;
+      continue;
+    }
     const float* acc = nullptr;   // nullptr: accumulator still equals y
     for (int s = 0; s < tab.stages; ++s) {
-      ddd::SubstepArgs a{};
-      a.t = t + tab.c[s] * dt;
-      a.y_in = s == 0 ? y : ystage;
-      a.batch = batch;
       const bool last = s == tab.stages - 1;
-      if (!last) {   // next stage input  y + a_{s+1} h f
-        a.y_base = y; a.c1 = tab.a[s + 1] * h; a.y_out = ystage;
+      const bool accumulate = tab.b[s] != 0.0f || last;
+      for (int hf = 0; hf < halves; ++hf) {
+        const size_t off = half_off[hf];
+        ddd::SubstepArgs a{};
+        a.t = t + tab.c[s] * dt;
+        a.y_in = (s == 0 ? y : ystage) + off;
+        a.batch = half_batch[hf];
+        if (!last) {   // next stage input  y + a_{s+1} h f
+          a.y_base = y + off; a.c1 = tab.a[s + 1] * h; a.y_out = ystage + off;
+        }
+        if (accumulate) {
+          a.acc_in = (acc != nullptr ? acc : y) + off;
+          a.c2 = tab.b[s] * h;
+          a.acc_out = ynew + off;
+        }
+        rc = launch_substep(m, a, lanes[hf], hf == 0 ? 0 : half_batch[0], halves);
+        if (rc) return rc;
       }
-      if (tab.b[s] != 0.0f || last) {
-        a.acc_in = acc != nullptr ? acc : y;
-        a.c2 = tab.b[s] * h;
-        a.acc_out = ynew;
-        acc = ynew;
-      }
-      rc = launch_substep(m, a, stream);
-      if (rc) return rc;
+      if (accumulate) acc = ynew;
     }
     y = ynew;
     if (saving) ++snap;
+  }
+  if (halves == 2) {
+    for (int i = 0; i < 2; ++i) {
+      DDD_HIP(hipEventRecord(m->ev_join[i], lanes[i]));
+      DDD_HIP(hipStreamWaitEvent(stream, m->ev_join[i], 0));
+    }
+    m->last_batch = batch;
   }
   return DDD_OK;
 }

@@ -119,6 +119,15 @@ struct AdaptiveArgs {
   long long max_attempts;   // safety net against runaway samples (SciPy has none)
 };
 
+// One whole Runge-Kutta step in one launch (DDD_LAUNCH_PER_STEP; rhs_mfma.h: step_multi_kernel)
+struct StepArgs {
+  double t, dt;
+  Tableau tab;
+  const float* y_in;
+  float* y_out;
+  int batch;
+};
+
 struct SubstepArgs {
   double t;
   const float* y_in;

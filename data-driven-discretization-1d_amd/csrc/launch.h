@@ -26,6 +26,10 @@ template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
                   hipStream_t stream);
 
+// all stages of one step in one launch (step_multi_kernel)
+template <int kEq>
+void step_spec(int rows, const DevParams& p, const StepArgs& a, int groups, int grid,
+               hipStream_t stream);
 // adaptive RK23, one controller per sample (rhs_adaptive.h); rows: 64 or 256
 template <int kEq>
 void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int blocks,
@@ -37,7 +41,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
   template <> void substep_spec<EQ>(int, const DevParams&, const SubstepArgs&, int, int,       \
                                     hipStream_t);                                              \
   template <> void adaptive_spec<EQ>(int, const DevParams&, const AdaptiveArgs&, int,          \
-                                     hipStream_t);
+                                     hipStream_t);                                             \
+  template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t);
 DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
 DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
 #undef DDD_DECLARE_SPEC

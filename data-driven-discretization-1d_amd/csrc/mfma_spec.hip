@@ -51,6 +51,17 @@ void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, in
 }
 
 template <>
+void step_spec<DDD_EQ>(int rows, const DevParams& p, const StepArgs& a, int groups,
+                       int grid, hipStream_t stream) {
+  if (rows == 64)
+    hipLaunchKernelGGL((mfma::step_multi_kernel<64, 64, DDD_EQ>), dim3(grid), dim3(64), 0,
+                       stream, p, a, groups);
+  else
+    hipLaunchKernelGGL((mfma::step_multi_kernel<256, 64, DDD_EQ>), dim3(grid), dim3(256), 0,
+                       stream, p, a, groups);
+}
+
+template <>
 void adaptive_spec<DDD_EQ>(int rows, const DevParams& p, const AdaptiveArgs& a, int blocks,
                            hipStream_t stream) {
   if (rows == 64)

@@ -64,7 +64,8 @@ struct Shared {
   float hA[kRows * kHS];
   float hB[kRows * kHS];
   float u[kRows];
-  float un[kRows];                // u / standard_deviation (input-layer operand)
+  float un[kRows == kWR ? 1 : kRows];   // u / standard_deviation (input-layer operand; one-wave
+                                        // groups feed the input layer by lane permutes)
   float flux[kRows == kWR ? 1 : kRows];  // one-wave groups exchange flux by shuffle
   float2 pm[kPmMax + 8];          // per (sample, mode): a sin(psi), a cos(psi); + read-ahead padding
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
@@ -73,9 +74,25 @@ struct Shared {
 };
 static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
 static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
+static_assert(8 * sizeof(Shared<64>) <= 158 * 1024, "2 x four-group workgroups per CU, with slack");
 static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
 static_assert(sizeof(Shared<64, 64, true>) <= 22 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
               "wide flavour: 7 x 64-row / 2 x 256-row workgroups per CU");
+
+// A one-wave row group (kRows == kWR) may be one of several INDEPENDENT groups
+// sharing a workgroup (substep_quad_kernel): its thread index is the lane, and
+// its "barrier" must not involve the other wavefronts -- within one wavefront
+// LDS operations execute in order, so waiting for them to land is all a barrier
+// means (and all `__syncthreads()` compiles to in a 64-thread workgroup).
+template <int kRows, int kWR>
+__device__ __forceinline__ int group_tid() {
+  return kRows == kWR ? ((int)threadIdx.x & 63) : (int)threadIdx.x;
+}
+template <int kRows, int kWR>
+__device__ __forceinline__ void group_barrier() {
+  if (kRows == kWR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  else __syncthreads();
+}
 
 // Value the optimiser must treat as unknown: stops loop-invariant code motion
 // from hoisting per-evaluation index math and loads out of the time loop (where
@@ -584,7 +601,7 @@ template <int kRows, int kWR, bool kWide>
 __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
-  __syncthreads();
+  group_barrier<kRows, kWR>();
   return forcing_phase2<kRows, kWR>(sm, res);
 }
 
@@ -606,7 +623,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                           float* coeffs_out, bool prepare_next = true,
                                           int group = -1, int ablate = 0,
                                           unsigned long long* trace = nullptr) {
-#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && (int)threadIdx.x == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define DDD_STAMP(i) do { if (kTrace && trace != nullptr && group_tid<kRows, kWR>() == 0) trace[i] = __builtin_amdgcn_s_memtime(); } while (0)
   DDD_STAMP(0);
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
   constexpr bool kSpec = kEq >= 0;
@@ -643,7 +660,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   constexpr bool kKeepOffsets = kWR == 64 && kHoist;
   constexpr bool kKeepRows = kKeepOffsets && kEq >= 0;
   constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
-  const int tid = opaque((int)threadIdx.x);
+  const int tid = opaque(group_tid<kRows, kWR>());
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
   if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
@@ -681,7 +698,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // previous evaluation (or the launch prologue), published here
   // (after the barrier: slower wavefronts may still be reading sm.fk in the
   // epilogue of the previous evaluation; the next barrier orders the readers)
-  __syncthreads();
+  group_barrier<kRows, kWR>();
   const bool trig_lds = p.n_k <= 4;   // cos/sin table staged in the LDS row padding
   if (forced && fast_forcing && res.frc_slot >= 0)   // (an empty run publishes its 0)
     sm.fk[res.frc_slot] = res.fk_next;
@@ -724,7 +741,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
       if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
-      __syncthreads();
+      group_barrier<kRows, kWR>();
       hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act);
       float* tmp = in; in = out; out = tmp;
     }
@@ -749,12 +766,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       }
       // the hidden layer's last activations are on their way to LDS: fill the
       // wait with the forcing sums the next evaluation needs
-      if (nL == 2) __syncthreads();   // no hidden layer: phase 1 -> phase 2 ordering
+      if (nL == 2) group_barrier<kRows, kWR>();   // no hidden layer: phase 1 -> phase 2 ordering
       // (masked sums where registers allow: the folded kernels; the unfolded
       // non-flux Burgers kernel needs them for the projection)
       constexpr bool kMaskedSums = kKeepRows && spec_folded(kSpec ? kEq : 0);
       if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
-      __syncthreads();
+      group_barrier<kRows, kWR>();
       if constexpr (kSpec) {
         f32x4 acc4[kNG];
         if (!(ablate & 4)) {
@@ -845,7 +862,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   } else {
     if (forced && fast_forcing && prepare_next && !(ablate & 1))
       res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_next, tid);
-    __syncthreads();   // all patch reads done before the next evaluation rewrites sm.u
+    group_barrier<kRows, kWR>();   // all patch reads done before the next evaluation rewrites sm.u
   }
 
   // ---- projection onto the accuracy-constrained stencils + stencil apply -----
@@ -1003,7 +1020,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                     : wrap_row(ln.base, ln.pos, 1, p.N), 64);
     } else {
       if (ln.owner) sm.flux[ln.row] = r;
-      __syncthreads();
+      group_barrier<kRows, kWR>();
       fnext = sm.flux[wrap_row(ln.base, ln.pos, 1, p.N)];
     }
     r = p.inv_dx * (fnext - r);      // equations.staggered_first_derivative
@@ -1052,7 +1069,7 @@ template <int kRows, int kWR, bool kHoist, bool kWide>
 __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               const Lane& ln, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
-  const int tid = (int)threadIdx.x;
+  const int tid = group_tid<kRows, kWR>();
   constexpr int kGW = flavour_stencil(kWide);
   for (int i = tid; i < tab_rows(kWide) * kGW; i += kThreads) {
     const int rowi = i / kGW, g = i % kGW;
@@ -1150,7 +1167,7 @@ struct SampleSetup {
 template <int kRows, int kWR>
 __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int block, int batch,
                                                      bool fast) {
-  const int tid = (int)threadIdx.x;
+  const int tid = group_tid<kRows, kWR>();
   const int spg = kRows / p.N;
   SampleSetup s{0.0f, 0.0f, 0.0f, 0};
   if (fast && tid < spg * p.P) {
@@ -1189,7 +1206,7 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide>& sm, Res
   for (int i = 0; i < 8; ++i) res.frc_mask[i] = i < cnt ? 1.0f : 0.0f;
   if (kReset) {
     res.fk_next = 0.0f;
-    for (int i = (int)threadIdx.x; i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
+    for (int i = group_tid<kRows, kWR>(); i < Shared<kRows, kWR>::kFkMax; i += kThreads) sm.fk[i] = 0.0f;
   }
 }
 
@@ -1232,30 +1249,32 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams 
 // resident and walks over `groups / gridDim.x` row groups.  A launch per group
 // (kernel 1) makes every wavefront fetch its 29 KB of weights again -- 120 MB of
 // L2 traffic per substep at batch 4096 -- and pays a second dispatch round.
+// The walk of one row-group slot: `first` = its first row group, `stride` = the
+// number of slots of the launch.
 template <int kRows, int kWR, int kEq>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevParams p,
-                                                                            SubstepArgs a,
-                                                                            int groups) {
-  __shared__ Shared<kRows, kWR> sm;
-  Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
+__device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepArgs& a,
+                                             Shared<kRows, kWR>& sm, int groups, int first,
+                                             int stride) {
+  const int tid = group_tid<kRows, kWR>();
+  Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, first);
   Resident res;
   // the first group's state and forcing rows are requested BEFORE the 115 weight
   // registers: its input layer and forcing sums run while the hidden layer's
   // weights are still arriving (loads return in order)
   float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;
   const bool fast_frc = forcing_is_fast<kRows, kWR>(p);
-  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, blockIdx.x, a.batch, fast_frc);
+  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, first, a.batch, fast_frc);
   setup_weights<kRows, kWR, true>(p, sm, ln, res);
   apply_samples<kRows, kWR>(sm, res, s_first);
-  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
-  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, tid);
+  for (int grp = first; grp < groups; grp += stride) {
     // the next group's state and forcing rows: in flight during this evaluation
-    const int nxt = grp + (int)gridDim.x;
+    const int nxt = grp + stride;
     const bool more = nxt < groups;
     Lane ln_next = ln;
     float u_next = 0.0f;
     if (more) {
-      ln_next = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, nxt);
+      ln_next = make_lane<kRows, kWR>(p, a.batch, tid, nxt);
       u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
       // from here on the harmonic sums computed are the NEXT group's: this
       // group's are already in res.fk_next and are published by eval_rhs
@@ -1279,7 +1298,76 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
       if (a.acc_out != nullptr) a.acc_out[ln.gidx] = acc_in + a.c2 * f;
     }
     if (more) {
-      __syncthreads();   // this group's epilogue has read sm.fk / sm.u
+      group_barrier<kRows, kWR>();   // this group's epilogue has read sm.fk / sm.u
+      ln = ln_next;
+      u = u_next;
+    }
+  }
+}
+
+template <int kRows, int kWR, int kEq>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevParams p,
+                                                                            SubstepArgs a,
+                                                                            int groups) {
+  __shared__ Shared<kRows, kWR> sm;
+  substep_walk<kRows, kWR, kEq>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// (Four independent one-wave groups per 256-thread workgroup -- which would put
+// exactly one wavefront of a launch on every SIMD, where one-wave workgroups
+// land two on one SIMD and none on another for ~10 % of the SIMDs -- was
+// measured slower: 35.1 vs 33.0 us per substep at B = 4096, the per-wavefront LDS
+// base costs registers the walk does not have.  profiles/r3_ablation.txt.)
+
+// Kernel 1c: ALL stages of one Runge-Kutta step in one launch, for callers that
+// do not need the substeps (DDD_LAUNCH_PER_STEP): the same walk over row groups
+// with the stage loop of the persistent integrator inside -- the state crosses
+// HBM once per step and the launch boundary is paid once per step.
+template <int kRows, int kWR, int kEq>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevParams p, StepArgs a,
+                                                                         int groups) {
+  __shared__ Shared<kRows, kWR> sm;
+  const int tid = group_tid<kRows, kWR>();
+  const int stride = (int)gridDim.x;
+  Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, (int)blockIdx.x);
+  Resident res;
+  float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;
+  const bool fast_frc = forcing_is_fast<kRows, kWR>(p);
+  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, blockIdx.x, a.batch, fast_frc);
+  setup_weights<kRows, kWR, true>(p, sm, ln, res);
+  apply_samples<kRows, kWR>(sm, res, s_first);
+  const float h = (float)a.dt;
+  const float t_first = (float)(a.t + a.tab.c[0] * a.dt);
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_first, tid);
+  for (int grp = blockIdx.x; grp < groups; grp += stride) {
+    const int nxt = grp + stride;
+    const bool more = nxt < groups;
+    Lane ln_next = ln;
+    float u_next = 0.0f;
+    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0};
+    if (more) {   // in flight during this group's stages
+      ln_next = make_lane<kRows, kWR>(p, a.batch, tid, nxt);
+      u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
+      s_next = fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc);
+    }
+    const float y = u;
+    float ynew = y, kprev = 0.0f;
+    for (int s = 0; s < a.tab.stages; ++s) {
+      const float us = s > 0 ? y + kprev * (a.tab.a[s] * h) : y;
+      const bool last = s + 1 == a.tab.stages;
+      // sums prepared inside this evaluation: this group's next stage, or -- in
+      // its last stage -- the NEXT group's first stage (other samples, same step)
+      if (last && more) apply_samples<kRows, kWR, false>(sm, res, s_next);
+      const float tn = last ? t_first : (float)(a.t + a.tab.c[s + 1] * a.dt);
+      const float f = eval_rhs<kRows, kWR, true, kEq, false>(
+          p, sm, a.batch, us, (float)(a.t + a.tab.c[s] * a.dt), tn, res, fast_frc, nullptr,
+          nullptr, !last || more, grp);
+      if (a.tab.b[s] != 0.0f) ynew = ynew + (a.tab.b[s] * h) * f;
+      kprev = f;
+    }
+    if (ln.active) a.y_out[ln.gidx] = ynew;
+    if (more) {
+      group_barrier<kRows, kWR>();
       ln = ln_next;
       u = u_next;
     }

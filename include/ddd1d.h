@@ -107,7 +107,10 @@ typedef enum ddd_kernel_kind {
 /* How ddd_integrate_fixed advances time. */
 typedef enum ddd_launch_mode {
   DDD_LAUNCH_PERSISTENT = 0, /* time loop inside ONE launch, state in registers */
-  DDD_LAUNCH_PER_SUBSTEP = 1 /* one fused launch per RK substep, state in HBM   */
+  DDD_LAUNCH_PER_SUBSTEP = 1, /* one fused launch per RK substep, state in HBM  */
+  DDD_LAUNCH_PER_STEP = 2 /* all stages of a step in one launch, state through HBM
+                           * once per step (models on a per-equation MFMA kernel;
+                           * others advance substep by substep)                */
 } ddd_launch_mode;
 
 /* Static description of one model: the equation (equations.py), the solution

@@ -4,7 +4,7 @@ import torch
 import ddd1d_amd
 lib = ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build_probe)
 torch.zeros(1).cuda()
-blocks = 2048
+blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 out = np.zeros((blocks, 4), dtype=np.uint32)
 lib.ddd_debug_hwid.restype = ctypes.c_int
 rc = lib.ddd_debug_hwid(out.ctypes.data_as(ctypes.c_void_p), blocks, 200000)
@@ -20,3 +20,5 @@ sizes = collections.Counter(len(v) for v in key.values())
 print('waves per (xcc,se,sh,cu,simd):', sizes, 'distinct SIMDs', len(key))
 for k in list(key)[:12]:
     print(k, key[k])
+per_cu = collections.Counter((int(xcc[b]), int(se[b]), int(sh[b]), int(cu[b])) for b in range(blocks))
+print('workgroups per CU:', collections.Counter(per_cu.values()), 'distinct CUs', len(per_cu))

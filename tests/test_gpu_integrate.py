@@ -65,12 +65,17 @@ def test_launch_modes_agree():
     b = model.integrate_fixed(y0, 12, dt=1e-3, scheme=scheme, save_every=4,
                               launch_mode='per_substep').cpu().numpy()
     np.testing.assert_array_equal(a, b)
+    # all stages of a step in one launch (DDD_LAUNCH_PER_STEP)
+    c = model.integrate_fixed(y0, 12, dt=1e-3, scheme=scheme, save_every=4,
+                              launch_mode='per_step').cpu().numpy()
+    np.testing.assert_array_equal(a, c)
 
 
 @pytest.mark.parametrize('equation,num_points,batch', [
     ('burgers', 64, 5003),    # one-wave groups: the grid is capped at two per SIMD, so
     ('burgers', 32, 5003),    # every wavefront walks over 2-3 groups (ragged tail)
-    ('kdv', 64, 4100),
+    ('kdv', 64, 4100),        # (>= 4096 groups: two half-ensembles on two streams)
+    ('burgers', 64, 8200),
     ('burgers', 128, 1501),   # 256-row groups, two samples each, last group half empty
 ])
 def test_launch_modes_agree_when_groups_outnumber_the_grid(equation, num_points, batch):
@@ -90,6 +95,9 @@ def test_launch_modes_agree_when_groups_outnumber_the_grid(equation, num_points,
   b = model.integrate_fixed(y0, 6, dt=dt, scheme='midpoint', save_every=3,
                             launch_mode='per_substep').cpu().numpy()
   np.testing.assert_array_equal(a, b)
+  c = model.integrate_fixed(y0, 6, dt=dt, scheme='midpoint', save_every=3,
+                            launch_mode='per_step').cpu().numpy()
+  np.testing.assert_array_equal(a, c)
   assert np.isfinite(b).all()
   rows = np.array([0, batch // 2, batch - 2, batch - 1])     # first and later passes
   sub_forcing = None if forcing is None else {k: v[rows] for k, v in forcing.items()}
@@ -122,6 +130,10 @@ def test_trajectories_on_grids_that_are_not_powers_of_two(equation, num_points, 
   b = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps // 2,
                             launch_mode='per_substep').cpu().numpy()
   np.testing.assert_array_equal(a, b)
+  c = model.integrate_fixed(y0, steps, dt=dt, scheme='bs3', save_every=steps // 2,
+                            launch_mode='per_step').cpu().numpy()
+  np.testing.assert_array_equal(c, model.integrate_fixed(
+      y0, steps, dt=dt, scheme='bs3', save_every=steps // 2).cpu().numpy())
   want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps,
                                 steps // 2, y0, forcing=forcing)
   err = rel_err(a, want)
