@@ -43,7 +43,7 @@ At N = 1 the same run also measures, each over its own >= --config-timed-ms
 timed region and each with its roofline fraction, the rest of the contract
 (reported under "configs"): BASELINE configs[2] (KdV N=64 B=4096) and
 configs[3] (KS N=256 B=8192), the headline workload with ONE FUSED LAUNCH PER
-RK SUBSTEP (north_star's literal structure), the HBM-bound fixed-stencil
+RK SUBSTEP (north_star's literal structure) and per RK step, the HBM-bound fixed-stencil
 streaming kernel (GB/s against the HBM peak), the batch-1
 `SavedModelDifferentiator.__call__` latency a SciPy caller sees, and the
 on-device adaptive RK23 (the reference's production integrator, one controller
@@ -75,8 +75,8 @@ PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
 TRAFFIC_TABLES = ('r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
 
 
-CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'stream_fixed',
-                'differentiator_b1', 'adaptive_rk23')
+CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
+                'stream_fixed', 'differentiator_b1', 'adaptive_rk23')
 
 
 def parse_args(argv=None):
@@ -638,8 +638,16 @@ def extra_configs(args, lib, world):
     elif name == 'burgers_per_substep':
       key, val = _fixed_step_config(
           args, lib, world, name, 'the headline workload with ONE FUSED LAUNCH PER RK '
-          'SUBSTEP (north_star structure; state through HBM every substep)', 4096,
+          'SUBSTEP for every sample (north_star structure; state through HBM every substep; '
+          'the ensemble advances as two half-ensembles on two streams, launches side by side)',
+          4096,
           **dict(base, launch_mode='per_substep', steps=200))
+    elif name == 'burgers_per_step':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the headline workload with one launch per RK STEP (all '
+          'stages fused, state through HBM once per step): for callers that need the host '
+          'between steps but not between substeps', 4096,
+          **dict(base, launch_mode='per_step', steps=200))
     elif name == 'stream_fixed':
       key, val = _fixed_step_config(
           args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '

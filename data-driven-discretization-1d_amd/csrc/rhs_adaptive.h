@@ -58,7 +58,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
                                                                        AdaptiveArgs a) {
   __shared__ Shared<kRows, kWR, kWide> sm;
   __shared__ double red[kRows == kWR ? 2 : kRows];
-  __shared__ float tev[kRows / 8];   // evaluation time of each sample of the group (N >= 8)
+  // evaluation time of each sample of the group (N >= 8), and of its NEXT evaluation
+  __shared__ float tev[kRows / 8], tev_next[kRows / 8];
   const int tid = (int)threadIdx.x;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, (int)blockIdx.x);
   Resident res;
@@ -93,24 +94,33 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
   // phase 0: f(t0, y0); 1: the probe of select_initial_step; 2..4: stages 2, 3
   // and the FSAL stage of one attempt.  Uniform over the workgroup.
   int phase = 0;
+  bool sums_ready = false;   // res.fk_next already holds the forcing sums of this evaluation
   for (;;) {
-    double tt, yy;
-    if (phase == 0) { tt = c.t; yy = y; }
-    else if (phase == 1) { tt = c.t + h0; yy = y + h0 * (double)k0; }
-    else if (phase == 2) { tt = c.t + 0.5 * c.h; yy = rk23::stage2_input(y, k0, c.h); }
-    else if (phase == 3) { tt = c.t + 0.75 * c.h; yy = rk23::stage3_input(y, k0, k1, c.h); }
-    else { tt = c.t + c.h; yy = y_new; }
-    if (c.status != rk23::RUNNING) { tt = c.t; yy = y; }   // idle samples stay finite
+    double tt, yy, tt_next;
+    if (phase == 0) { tt = c.t; yy = y; tt_next = tt; }
+    else if (phase == 1) { tt = c.t + h0; yy = y + h0 * (double)k0; tt_next = tt; }
+    else if (phase == 2) {
+      tt = c.t + 0.5 * c.h; yy = rk23::stage2_input(y, k0, c.h); tt_next = c.t + 0.75 * c.h;
+    } else if (phase == 3) {
+      tt = c.t + 0.75 * c.h; yy = rk23::stage3_input(y, k0, k1, c.h); tt_next = c.t + c.h;
+    } else { tt = c.t + c.h; yy = y_new; tt_next = tt; }
+    if (c.status != rk23::RUNNING) { tt = c.t; yy = y; tt_next = c.t; }   // idle samples stay finite
 
+    // Harmonic forcing sums at THIS sample's time.  Inside an attempt the next
+    // stage's time is known, so stages 3 and 4 get their sums from the look-ahead
+    // of the evaluation before them (as the fixed-step integrators do); the first
+    // stage of an attempt cannot: its time depends on the error test.
+    const bool ahead = fast_frc && (phase == 2 || phase == 3);
+    float tn_lane = (float)tt;
     if (fast_frc) {
-      // harmonic forcing sums at THIS sample's time (no look-ahead: the next
-      // evaluation's time is not known before the error test)
-      if (row_live && ln.pos == 0) tev[ln.sl] = (float)tt;
+      if (row_live && ln.pos == 0) { tev[ln.sl] = (float)tt; tev_next[ln.sl] = (float)tt_next; }
       __syncthreads();
-      res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, tev[frc_sl], tid);
+      if (!sums_ready) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, tev[frc_sl], tid);
+      tn_lane = tev_next[frc_sl];
     }
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false>(
-        p, sm, a.batch, (float)yy, (float)tt, (float)tt, res, fast_frc, nullptr, nullptr, false);
+        p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
+    sums_ready = ahead;
     if (c.status == rk23::RUNNING) ++c.nfev;
 
     if (phase == 0) {

@@ -51,7 +51,7 @@ def test_bench_defaults_match_baseline_config():
   assert args.preheat_ms >= 200.0 and args.min_timed_ms >= 1000.0
   # the rest of the contract rides in the same run at N = 1
   assert args.configs == 'all' and set(bench.CONFIG_NAMES) >= {
-      'kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'stream_fixed',
+      'kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step', 'stream_fixed',
       'differentiator_b1', 'adaptive_rk23'}
   # BASELINE configs[4]: 65 536 samples over 8 GPUs = 8 192 per GPU
   assert bench.parse_args(['--gpus', '8']).batch == 8192
