@@ -101,6 +101,21 @@ __device__ __forceinline__ int opaque(int x) {
   asm volatile("" : "+v"(x));
   return x;
 }
+// Same for a wave-uniform value that must STAY scalar.  Without it the
+// run-time-parameterised kernels hoist every predicate derived from the model
+// parameters (g < G, d < D, the per-channel derivative selectors ...) out of the
+// time loop as 64-bit lane masks -- ~60 SGPR pairs, spilled to VGPR lanes and
+// read back with v_readlane (~100 VALU-issue slots per evaluation, which the f32
+// MFMA stream pays for one to one); opaque, they are recomputed on the scalar
+// unit inside each evaluation, which costs nothing.
+__device__ __forceinline__ int opaque_scalar(int x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
+__device__ __forceinline__ unsigned long long opaque_scalar(unsigned long long x) {
+  asm volatile("" : "+s"(x));
+  return x;
+}
 
 // Compile-time specialisation of the evaluation on the equation (kEq >= 0):
 // derivative count, stencil width and flux form become constants, the net is
@@ -628,8 +643,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // run-time parameters, or compile-time constants when specialised (kEq >= 0)
   constexpr bool kSpec = kEq >= 0;
   const int eqn = kSpec ? kEq : p.equation;
-  const int nD = kSpec ? spec_derivs(kEq) : p.D;
-  const int nG = kSpec ? spec_stencil(kEq) : p.G;
+  const int nD = kSpec ? spec_derivs(kEq) : opaque_scalar(p.D);
+  const int nG = kSpec ? spec_stencil(kEq) : opaque_scalar(p.G);
+  const unsigned dsel_valid = kSpec ? 0u : (unsigned)opaque_scalar((int)p.dsel_valid);
+  const unsigned long long dsel_bits = kSpec ? 0ull : opaque_scalar(p.dsel_bits);
+  const int rt_groups = kSpec ? 0 : opaque_scalar(p.rt_groups);
   const bool flux_form = kSpec ? spec_flux_form(kEq) : (p.conservative != 0);
   const bool fixed = kSpec ? false : (p.fixed != 0);
   const bool folded = kSpec ? spec_folded(kSpec ? kEq : 0) : (p.folded != 0);
@@ -727,16 +745,6 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                                act, res.in_perm);
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
-    // output layer weights that are not resident: requested now, an L2 latency
-    // ahead of the hidden layer's ~10 k cycles of MFMAs
-    // (run-time kernels: the first chunk, up to three groups)
-    constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs(3);
-    float wf4[kFirstRows];
-    if (!kKeepRows) {
-      const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
-#pragma unroll
-      for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
-    }
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
@@ -748,7 +756,15 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     DDD_STAMP(2);
     {
       // output layer: weights resident (specialised one-wave integrators) or
-      // fetched from L2 above
+      // fetched from L2 here, in flight across the forcing sums below
+      // (run-time kernels: the first chunk, up to three groups)
+      constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs(3);
+      float wf4[kFirstRows];
+      if (!kKeepRows) {
+        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
+#pragma unroll
+        for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
+      }
       int off4[kKW];
       if (kKeepRows) {
 #pragma unroll
@@ -793,7 +809,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
         // with 16 instead of the same.  Wave-uniform branches; every chunk's
         // weights are fetched while the previous chunk's MFMAs run.
         constexpr int kPairRows = fin4_regs(2);
-        const int head = rt_head_groups(p.rt_groups);
+        const int head = rt_head_groups(rt_groups);
         int done = 0;   // groups issued so far
         if (!(ablate & 4)) {
           float wnext[kPairRows];
@@ -804,7 +820,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
 #pragma unroll
             for (int s2 = 0; s2 < kPairRows; ++s2) wnext[s2] = wn[s2 * 64];
           };
-          if (head > 0 && head < p.rt_groups) fetch_pair(head);   // (head 0: pair 0 is in wf4)
+          if (head > 0 && head < rt_groups) fetch_pair(head);   // (head 0: pair 0 is in wf4)
           if (head == 3) {
             f32x4 acc3[3];
             final_layer4<3>(in, wf4, off4, acc3);
@@ -825,11 +841,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
           // pairs: group index 2 j (head 0) or 2 j + 1 (odd head): compile-time slots
 #pragma unroll
           for (int j = 0; j < kCh / 8; ++j) {
-            if (done >= p.rt_groups) break;
+            if (done >= rt_groups) break;
             float w2[kPairRows];
 #pragma unroll
             for (int s2 = 0; s2 < kPairRows; ++s2) w2[s2] = (head == 0 && j == 0) ? wf4[s2] : wnext[s2];
-            if (done + 2 < p.rt_groups) fetch_pair(done + 2);
+            if (done + 2 < rt_groups) fetch_pair(done + 2);
             f32x4 acc2[2];
             final_layer4<2>(in, w2, off4, acc2);
             if (head == 0) {
@@ -930,9 +946,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // specialised kernels: the null-space split is known (spec_in_size, checked
       // by capi.hip: spec_equation), so the channel -> derivative map is a
       // compile-time constant
-      if (kSpec ? c >= spec_net_channels(kSpec ? kEq : 0) : !((p.dsel_valid >> c) & 1u)) continue;
+      if (kSpec ? c >= spec_net_channels(kSpec ? kEq : 0) : !((dsel_valid >> c) & 1u)) continue;
       const unsigned d = kSpec ? (unsigned)spec_channel_deriv(kSpec ? kEq : 0, c)
-                               : (unsigned)(p.dsel_bits >> (2 * c)) & 3u;
+                               : (unsigned)(dsel_bits >> (2 * c)) & 3u;
       const float nv = net[c];
       float nsr[kGW];
 #pragma unroll

@@ -1,0 +1,43 @@
+#!/bin/bash
+# Round-3 measurement run (one gpurun call): the full bench line un-profiled,
+# rocprofv3 kernel trace + stats of the same command, PMC passes (FETCH_SIZE and
+# WRITE_SIZE in SEPARATE runs, SQ counters in their own), phase traces from the
+# probe library.  Outputs under gpurun_out/r3prof/ (scratch);
+# profiles/tools/summarize_r3.py turns them into the committed profiles/r3_*.
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r3prof
+rm -rf $O; mkdir -p $O
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $O/smoke.txt
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+B="python bench.py --configs none --secondary-batch 0 --cpu-seconds 0"
+prof() {  # tag, extra rocprofv3 flags..., -- , bench flags
+  local tag=$1; shift
+  local flags=(); while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
+  timeout 600 rocprofv3 --kernel-trace "${flags[@]}" --output-format csv -d $O/$tag -o run -- $B "$@" > $O/$tag.log 2>&1
+}
+# kernel stats of the default command (every kernel of the line) and of the headline alone
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -o run -- python bench.py --cpu-seconds 0 > $O/stats_default.log 2>&1
+prof stats_B4096 --stats -- --warmup 1000
+prof stats_B1024 --stats -- --batch 1024 --warmup 1000
+prof stats_persub --stats -- --launch-mode per_substep --steps 200 --warmup 200 --preheat-ms 50
+prof stats_perstep --stats -- --launch-mode per_step --steps 200 --warmup 200 --preheat-ms 50
+# HBM traffic: one counter per run
+short="--warmup 0 --preheat-ms 0 --min-timed-ms 0"
+for c in FETCH_SIZE WRITE_SIZE; do
+  prof pmc_${c}_B4096 --pmc $c -- --steps 1000 $short
+  prof pmc_${c}_B1024 --pmc $c -- --batch 1024 --steps 1000 $short
+  prof pmc_${c}_persub --pmc $c -- --launch-mode per_substep --steps 20 $short
+  prof pmc_${c}_perstep --pmc $c -- --launch-mode per_step --steps 20 $short
+  prof pmc_${c}_stream --pmc $c -- --equation kdv --baseline-stencils --launch-mode per_substep --batch 262144 --steps 20 $short
+  prof pmc_${c}_kdv --pmc $c -- --equation kdv --steps 1000 $short
+  prof pmc_${c}_ks256 --pmc $c -- --equation ks --num-points 256 --batch 8192 --steps 400 $short
+done
+prof pmc_sq_B4096 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -- --steps 1000 $short
+prof pmc_clk_B4096 --pmc GRBM_GUI_ACTIVE -- --steps 1000 --warmup 1000 --preheat-ms 200 --min-timed-ms 0
+timeout 300 python profiles/tools/trace_phases.py 1024 25 2>/dev/null | tail -7 > $O/phases_B1024.txt
+timeout 300 python profiles/tools/trace_phases.py 2048 25 2>/dev/null | tail -7 > $O/phases_B2048.txt
+timeout 300 python profiles/tools/trace_phases.py 2048 25 no_spec 2>/dev/null | tail -7 > $O/phases_B2048_runtime.txt
+find $O -name "*_kernel_trace.csv" -size +3M -delete
+find $O -name "*.db" -delete
+du -sh $O | tail -1; cat $O/smoke.txt; ls $O | head -50

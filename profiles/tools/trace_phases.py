@@ -6,6 +6,9 @@ ddd1d_amd._lib.load_probe_library()   # libddd1d_probe.so (__graft_entry__.build
 if 'no_spec' in sys.argv:   # trace the run-time-parameterised kernel instead of the per-equation one
     ddd1d_amd._lib.debug_set_option('no_spec', 1)
     sys.argv.remove('no_spec')
+for item in [a for a in sys.argv if a.startswith('ablate=')]:   # skip phases (WRONG results): 1 forcing, 2 projection, 4 output layer, 16 input layer
+    ddd1d_amd._lib.debug_set_option('ablate', int(item.split('=')[1]))
+    sys.argv.remove(item)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}))
 _, eq = equations.from_hparams(hp)
