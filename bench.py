@@ -72,7 +72,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
-TRAFFIC_TABLES = ('r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
+TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
 
 
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
