@@ -42,6 +42,7 @@ struct DebugOptions {
   int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
+  int substep_parts = 0; // A/B: sample slabs advanced side by side in the per-substep modes (0: auto)
   int ablate = 0;        // skips kernel phases: WRONG RESULTS (run-time-parameterised kernels)
   unsigned long long trace_ptr = 0;   // device buffer for s_memtime phase stamps
 };
@@ -188,8 +189,8 @@ struct ddd_model {
   // per-substep launch mode: the ensemble is advanced as two half-ensembles on two
   // internal streams, so that one half's launch boundary overlaps the other's
   // steady state (ddd_integrate_fixed)
-  hipStream_t aux_stream[2] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+  hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
   // output times of ddd_integrate_adaptive_f64
   double* d_times = nullptr;
   size_t times_capacity = 0;
@@ -1030,7 +1031,7 @@ int ddd_model_destroy(ddd_model* m) {
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   free_dev(m->d_times);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 4; ++i) {
     if (m->aux_stream[i] != nullptr) (void)hipStreamDestroy(m->aux_stream[i]);
     if (m->ev_join[i] != nullptr) (void)hipEventDestroy(m->ev_join[i]);
   }
@@ -1220,8 +1221,10 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   // other half's wavefronts have the matrix pipes to themselves, which a single
   // wavefront per SIMD nearly saturates.  Still one fused launch per substep for
   // every sample; results are bit-identical (same kernel, same arithmetic).
-  int halves = 1;
-  int half_batch[2] = {batch, 0};
+  constexpr int kMaxParts = 4;
+  int halves = 1;                                  // slabs advanced side by side
+  int half_batch[kMaxParts] = {batch, 0, 0, 0};
+  int slab_first[kMaxParts] = {0, 0, 0, 0};        // first sample of each slab
   int step_eq = -1;   // per-equation kernel for DDD_LAUNCH_PER_STEP
   if (m->kernel == DDD_KERNEL_MFMA && !m->explicit_kernel && !g_debug.no_spec) {
     const MfmaGeometry geo = mfma_geometry(m, batch);
@@ -1232,13 +1235,19 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
       step_eq = spec_equation(m, geo.rows);
     if (geo.wave_rows == 64 && spec_equation(m, geo.rows) >= 0 && groups >= 2 * capacity) {
       halves = 2;
-      half_batch[0] = ((groups + 1) / 2) * spg;   // whole workgroups
-      half_batch[1] = batch - half_batch[0];
+      if (g_debug.substep_parts > 0) halves = std::min(g_debug.substep_parts, kMaxParts);
+      const int per = ((groups + halves - 1) / halves) * spg;   // whole workgroups
+      int first = 0;
+      for (int i = 0; i < halves; ++i) {
+        slab_first[i] = first;
+        half_batch[i] = std::max(0, std::min(per, batch - first));
+        first += half_batch[i];
+      }
     }
   }
-  hipStream_t lanes[2] = {stream, stream};
-  if (halves == 2) {
-    for (int i = 0; i < 2; ++i) {
+  hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
+  if (halves > 1) {
+    for (int i = 0; i < halves; ++i) {
       if (m->aux_stream[i] == nullptr)
         DDD_HIP(hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking));
       if (m->ev_join[i] == nullptr)
@@ -1248,20 +1257,23 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     if (m->ev_fork == nullptr)
       DDD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     DDD_HIP(hipEventRecord(m->ev_fork, stream));
-    for (int i = 0; i < 2; ++i) DDD_HIP(hipStreamWaitEvent(lanes[i], m->ev_fork, 0));
-    // the second chain starts half a substep late (estimate: ~6 us per launch +
+    for (int i = 0; i < halves; ++i) DDD_HIP(hipStreamWaitEvent(lanes[i], m->ev_fork, 0));
+    // chain i starts i / halves of a launch late (estimate: ~6 us per launch +
     // ~14.5 us per row group a wavefront walks over; 100 ticks of s_memrealtime = 1 us)
     const MfmaGeometry geo = mfma_geometry(m, batch);
     const int spg = geo.rows / m->dp.N;
     const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
-    const int passes = ((half_batch[0] + spg - 1) / spg + capacity / 2 - 1) / (capacity / 2);
+    const int share = std::max(capacity / halves, 1);
+    const int passes = ((half_batch[0] + spg - 1) / spg + share - 1) / share;
     const double est_us = 6.0 + 14.5 * passes * (geo.rows == 64 ? 1.0 : 4.0) *
                                     (step_eq >= 0 ? tab.stages : 1);
-    hipLaunchKernelGGL(ddd::ops::delay_kernel, dim3(1), dim3(64), 0, lanes[1],
-                       (unsigned)(50.0 * est_us));
+    for (int i = 1; i < halves; ++i)
+      hipLaunchKernelGGL(ddd::ops::delay_kernel, dim3(1), dim3(64), 0, lanes[i],
+                         (unsigned)(100.0 * est_us * i / halves));
     DDD_HIP(hipGetLastError());
   }
-  const size_t half_off[2] = {0, (size_t)half_batch[0] * m->dp.N};
+  size_t half_off[kMaxParts];
+  for (int i = 0; i < kMaxParts; ++i) half_off[i] = (size_t)slab_first[i] * m->dp.N;
   const float* y = y0;
   size_t snap = 0;
   for (int step = 0; step < n_steps; ++step) {
@@ -1275,10 +1287,11 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
       const int spg = geo.rows / m->dp.N;
       const int capacity = (geo.rows == 64 ? 2 * device_simds() : device_simds() / 2) / halves;
       for (int hf = 0; hf < halves; ++hf) {
+        if (half_batch[hf] == 0) continue;
         ddd::DevParams dp = m->dp;
-        if (hf == 1 && dp.forced) {
-          dp.frc += (size_t)half_batch[0] * dp.P;
-          dp.runs += (size_t)half_batch[0] * 8;
+        if (slab_first[hf] != 0 && dp.forced) {
+          dp.frc += (size_t)slab_first[hf] * dp.P;
+          dp.runs += (size_t)slab_first[hf] * 8;
         }
         ddd::StepArgs sa{};
         sa.t = t; sa.dt = dt; sa.tab = tab;
@@ -1319,7 +1332,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
           a.c2 = tab.b[s] * h;
           a.acc_out = ynew + off;
         }
-        rc = launch_substep(m, a, lanes[hf], hf == 0 ? 0 : half_batch[0], halves);
+        rc = launch_substep(m, a, lanes[hf], slab_first[hf], halves);
         if (rc) return rc;
       }
       if (accumulate) acc = ynew;
@@ -1327,8 +1340,8 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     y = ynew;
     if (saving) ++snap;
   }
-  if (halves == 2) {
-    for (int i = 0; i < 2; ++i) {
+  if (halves > 1) {
+    for (int i = 0; i < halves; ++i) {
       DDD_HIP(hipEventRecord(m->ev_join[i], lanes[i]));
       DDD_HIP(hipStreamWaitEvent(stream, m->ev_join[i], 0));
     }
@@ -1654,7 +1667,8 @@ int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0;
 #ifdef DDD_PROBES
 // Profiling / A-B switches (not part of the product API; every change is
 // logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
-// no_stream, prio_split, stagger, ablate, trace_ptr.
+// no_stream, prio_split, stagger, substep_parts, ablate, trace_ptr; "reset" puts
+// every switch back to its default (the switches are process-global).
 int ddd_debug_set_option(const char* name, long long value) {
   if (name == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "name is NULL");
   const std::string key(name);
@@ -1663,6 +1677,8 @@ int ddd_debug_set_option(const char* name, long long value) {
   else if (key == "no_stream") g_debug.no_stream = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;
+  else if (key == "substep_parts") g_debug.substep_parts = (int)value;
+  else if (key == "reset") g_debug = DebugOptions{};   // every switch back to its default
   else if (key == "ablate") g_debug.ablate = (int)value;
   else if (key == "trace_ptr") g_debug.trace_ptr = (unsigned long long)value;
   else return fail(DDD_ERR_INVALID_ARGUMENT, "unknown debug option '%s'", name);

@@ -154,3 +154,49 @@ def test_bench_self_launches_its_ranks():
   result = json.loads(line)
   assert result['n_gpus'] == 2 and result['config']['global_batch'] == 4096
   assert result['config']['finite'] and result['value'] > 0
+
+
+def _eval_worker(rank, world, port, tmpdir):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank),
+                    WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                    HSA_ENABLE_IPC_MODE_LEGACY='0')
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  from test_gpu_evaluation import _setup
+  from helpers import random_phase_ic
+  from ddd1d_amd import evaluation
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  try:
+    hp, model = _setup('burgers', 7)
+    y0 = 0.3 * random_phase_ic(model.equation, 7)
+    times = np.arange(0, 0.2 + 1e-9, 0.1)
+    out = evaluation.run_integrate_batch(model, hp, y0, times)   # shard, adaptive RK23, gather
+    if rank == 0:
+      np.savez(os.path.join(tmpdir, 'eval.npz'), y=out['y'], num_evals=out['num_evals'],
+               sample=out['sample'])
+  finally:
+    dist.destroy_process_group()
+
+
+def test_two_ranks_evaluation_harness_adaptive(tmp_path):
+  """run_integrate_batch under two ranks (the analogue of the reference's Beam
+  fan-out + ConcatCombineFn('sample'), run_evaluation.py:212-221): each rank
+  integrates its ragged slab (4 + 3 samples) with the on-device adaptive RK23 and
+  its own seeds' forcing; trajectories AND per-sample evaluation counts are
+  gathered and equal the single-process run."""
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  mp.spawn(_eval_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  got = np.load(os.path.join(str(tmp_path), 'eval.npz'))
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  from test_gpu_evaluation import _setup
+  from helpers import random_phase_ic
+  from ddd1d_amd import evaluation
+  hp, model = _setup('burgers', 7)
+  y0 = 0.3 * random_phase_ic(model.equation, 7)
+  want = evaluation.run_integrate_batch(model, hp, y0, np.arange(0, 0.2 + 1e-9, 0.1))
+  assert got['y'].shape == (7, 3, 64) and got['y'].dtype == np.float64
+  np.testing.assert_array_equal(got['y'], want['y'])
+  np.testing.assert_array_equal(got['num_evals'], want['num_evals'])
+  np.testing.assert_array_equal(got['sample'], np.arange(7))
