@@ -1426,10 +1426,6 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     return fail(DDD_ERR_INVALID_ARGUMENT, "rtol and max_step must be positive, atol >= 0");
   if (batch > 0 && (!y0 || !y_out || !nfev || !status))
     return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
-  if (!m->spectral && m->kernel != DDD_KERNEL_MFMA)
-    return fail(DDD_ERR_UNSUPPORTED,
-                "the on-device adaptive integrator runs on the MFMA kernel family and on "
-                "spectral models only (%s)", m->mfma_reason.c_str());
   if (batch == 0) return DDD_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (m->times_capacity < (size_t)n_times) {
@@ -1471,6 +1467,20 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     else if (pts <= 4) DDD_SPECTRAL_ADAPTIVE(4);
     else DDD_SPECTRAL_ADAPTIVE(8);
 #undef DDD_SPECTRAL_ADAPTIVE
+    DDD_HIP(hipGetLastError());
+    return DDD_OK;
+  }
+  if (m->kernel != DDD_KERNEL_MFMA) {
+    // generic right-hand side (WENO5 exact solver, nets the MFMA path does not carry):
+    // one workgroup and one controller per sample
+    const size_t lds = ddd::generic::adaptive_lds_bytes(m->dp);
+    if (lds > 160 * 1024)
+      return fail(DDD_ERR_UNSUPPORTED,
+                  "generic adaptive kernel needs %zu B of LDS per sample (limit 163840)", lds);
+    DDD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ddd::generic::adaptive_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(ddd::generic::adaptive_kernel, dim3(batch), dim3(ddd::generic::kThreads),
+                       lds, stream, m->dp, a);
     DDD_HIP(hipGetLastError());
     return DDD_OK;
   }

@@ -9,6 +9,7 @@
 // and exists for coverage, not for speed.
 #pragma once
 #include "dev_params.h"
+#include "rk23.h"
 
 namespace ddd {
 namespace generic {
@@ -237,6 +238,144 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, Integr
       ++snap;
     }
     __syncthreads();
+  }
+}
+
+// Extra dynamic LDS of adaptive_kernel behind lds_bytes(p, 0): y, y_new
+// (float64) and three stage derivatives (float32) per grid point.
+__host__ __device__ inline size_t adaptive_lds_bytes(const DevParams& p) {
+  return ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (size_t)p.N * (2 * sizeof(double) + 3 * sizeof(float));
+}
+
+// integrate.odeint (integrate.py:143-169) for a batch of samples on the generic
+// right-hand side: SciPy's RK23 (rk23.h) with one workgroup and one controller
+// per sample, float64 state and controller, float32 right-hand side with the
+// sample's own forcing.  Serves what the MFMA path does not carry -- first of
+// all the WENO5 + Godunov-flux "exact" Burgers solver (WENODifferentiator,
+// integrate.py:124-140) on its fine grid.
+__global__ __launch_bounds__(kThreads) void adaptive_kernel(DevParams p, AdaptiveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ double red[4];
+  const Carve c = carve(p, smem);
+  const size_t front = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  double* y = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + front);
+  double* y_new = y + p.N;
+  float* k0 = reinterpret_cast<float*>(y_new + p.N);
+  float* k1 = k0 + p.N;
+  float* k2 = k1 + p.N;
+  const int n = p.N, tid = (int)threadIdx.x;
+  const long sample = blockIdx.x;
+  const size_t off = (size_t)sample * n;
+  const size_t row_stride = (size_t)a.batch * n;
+  for (int i = tid; i < n; i += kThreads) { y[i] = a.y0[off + i]; y_new[i] = y[i]; }
+  __syncthreads();
+
+  const double t0 = a.times[0];
+  const double t_bound = a.times[a.n_times - 1];
+  const double interval = fabs(t_bound - t0);
+  const double rtol = a.rtol, atol = a.atol, max_step = a.max_step;
+  const double sqrt_n = sqrt((double)n);
+  rk23::Control ctl;
+  ctl.init(t0, true);
+  double h0 = 0.0, d1 = 0.0;
+  long long attempts = 0;
+  int phase = 0;
+  while (ctl.status == rk23::RUNNING) {   // uniform over the workgroup
+    double tt;
+    if (phase == 0) tt = ctl.t;
+    else if (phase == 1) tt = ctl.t + h0;
+    else if (phase == 2) tt = ctl.t + 0.5 * ctl.h;
+    else if (phase == 3) tt = ctl.t + 0.75 * ctl.h;
+    else tt = ctl.t + ctl.h;
+    for (int i = tid; i < n; i += kThreads) {
+      double yy;
+      if (phase == 0) yy = y[i];
+      else if (phase == 1) yy = y[i] + h0 * (double)k0[i];
+      else if (phase == 2) yy = rk23::stage2_input(y[i], k0[i], ctl.h);
+      else if (phase == 3) yy = rk23::stage3_input(y[i], k0[i], k1[i], ctl.h);
+      else yy = y_new[i];
+      c.u[i] = (float)yy;
+    }
+    __syncthreads();
+    eval_rhs(p, c, sample, (float)tt, nullptr, nullptr);   // -> c.dy, ends with a barrier
+    ++ctl.nfev;
+    double part = 0.0;
+    if (phase == 0) {
+      for (int i = tid; i < n; i += kThreads) k0[i] = c.dy[i];
+      if (a.n_times == 1) {
+        for (int i = tid; i < n; i += kThreads) a.y_out[off + i] = y[i];
+        ctl.ti = 1;
+        ctl.status = rk23::FINISHED;
+      } else {
+        for (int i = tid; i < n; i += kThreads) {
+          const double q = y[i] / (atol + fabs(y[i]) * rtol);
+          part += q * q;
+        }
+        const double d0 = sqrt(rk23::block_sum256(part, red)) / sqrt_n;
+        part = 0.0;
+        for (int i = tid; i < n; i += kThreads) {
+          const double q = (double)c.dy[i] / (atol + fabs(y[i]) * rtol);
+          part += q * q;
+        }
+        d1 = sqrt(rk23::block_sum256(part, red)) / sqrt_n;
+        h0 = rk23::Control::first_guess(d0, d1, interval);
+      }
+      phase = 1;
+    } else if (phase == 1) {
+      for (int i = tid; i < n; i += kThreads) {
+        const double q = (double)(c.dy[i] - k0[i]) / (atol + fabs(y[i]) * rtol);   // float32 difference
+        part += q * q;
+      }
+      const double d2 = sqrt(rk23::block_sum256(part, red)) / sqrt_n / h0;
+      ctl.initial_step(h0, d1, d2, interval, max_step);
+      ctl.begin_step(max_step);
+      ctl.begin_attempt(t_bound);
+      phase = 2;
+    } else if (phase == 2) {
+      for (int i = tid; i < n; i += kThreads) k1[i] = c.dy[i];
+      phase = 3;
+    } else if (phase == 3) {
+      for (int i = tid; i < n; i += kThreads) {
+        k2[i] = c.dy[i];
+        y_new[i] = rk23::new_state(y[i], k0[i], k1[i], k2[i], ctl.h);
+      }
+      phase = 4;
+    } else {
+      for (int i = tid; i < n; i += kThreads) {
+        const double q = rk23::scaled_error(y[i], y_new[i], k0[i], k1[i], k2[i], c.dy[i], ctl.h,
+                                            rtol, atol);
+        part += q * q;
+      }
+      const double error_norm = sqrt(rk23::block_sum256(part, red)) / sqrt_n;
+      if (ctl.error_test(error_norm)) {
+        while (ctl.ti < a.n_times) {
+          const double te = a.times[ctl.ti];
+          if (!(te <= ctl.t_new)) break;
+          const double x = (te - ctl.t) / ctl.h;
+          for (int i = tid; i < n; i += kThreads)
+            a.y_out[(size_t)ctl.ti * row_stride + off + i] =
+                rk23::dense_output(y[i], k0[i], k1[i], k2[i], c.dy[i], x, ctl.h);
+          ++ctl.ti;
+        }
+        for (int i = tid; i < n; i += kThreads) { y[i] = y_new[i]; k0[i] = c.dy[i]; }
+        ctl.advance(t_bound, max_step);
+      }
+      ++attempts;
+      if (ctl.status == rk23::RUNNING && attempts >= a.max_attempts)
+        ctl.status = rk23::ATTEMPT_LIMIT;
+      ctl.begin_attempt(t_bound);
+      phase = 2;
+    }
+    __syncthreads();   // c.dy / k / y are rewritten by the next iteration
+  }
+  if (ctl.status != rk23::FINISHED) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int r = ctl.ti; r < a.n_times; ++r)
+      for (int i = tid; i < n; i += kThreads) a.y_out[(size_t)r * row_stride + off + i] = nan;
+  }
+  if (tid == 0) {
+    a.nfev[sample] = ctl.nfev;
+    a.status[sample] = ctl.status;
   }
 }
 

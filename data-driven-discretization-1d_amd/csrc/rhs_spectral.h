@@ -114,17 +114,6 @@ __device__ __forceinline__ void eval_points(const Params& p, const double* __res
   }
 }
 
-// Sum over the workgroup, identical on every thread: wave butterflies, then the
-// four wave totals in a fixed order.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const double s = ((red[0] + red[1]) + red[2]) + red[3];
-  __syncthreads();
-  return s;
-}
-
 // integrate.odeint over SpectralDifferentiator (integrate.py:108-121, 143-169)
 // for a batch of samples: SciPy's RK23 (rk23.h) with float64 right-hand side,
 // one workgroup and one controller per sample, kPts grid points per thread.
@@ -159,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void adaptive_kernel(Params p, AdaptiveAr
 #pragma unroll
     for (int i = 0; i < kPts; ++i)
       if (tid + i * kThreads < n) part += q[i] * q[i];
-    return sqrt(block_sum(part, red)) / sqrt_n;
+    return sqrt(rk23::block_sum256(part, red)) / sqrt_n;
   };
 
   rk23::Control ctl;

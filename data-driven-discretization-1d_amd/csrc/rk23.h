@@ -1,9 +1,11 @@
 // SciPy's RK23 step-size controller (scipy/integrate/_ivp: RungeKutta.__init__,
 // select_initial_step, RungeKutta._step_impl, rk_step, RkDenseOutput), the part
-// that is per SAMPLE and scalar, shared by the two on-device adaptive
+// that is per SAMPLE and scalar, shared by the three on-device adaptive
 // integrators:
-//   rhs_adaptive.h            learned / fixed stencils, float32 right-hand side
-//                             (integrate.SavedModelDifferentiator, integrate.py:48-71)
+//   rhs_adaptive.h            learned / fixed stencils on the MFMA kernels, float32
+//                             right-hand side (SavedModelDifferentiator, integrate.py:48-71)
+//   rhs_generic.h             the generic kernel: WENO5 + Godunov "exact" Burgers solver
+//                             (WENODifferentiator, integrate.py:124-140), any other net
 //   rhs_spectral.h            spectral "exact" solver, float64 right-hand side
 //                             (integrate.SpectralDifferentiator, integrate.py:108-121)
 // Call site in the reference: integrate.odeint, integrate.py:154-155
@@ -105,6 +107,17 @@ struct Control {
     else begin_step(max_step);
   }
 };
+
+// Sum over a 256-thread workgroup, identical (bitwise) on every thread: wave
+// butterflies, then the four wave totals in a fixed order.  `red`: 4 doubles of LDS.
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double s = ((red[0] + red[1]) + red[2]) + red[3];
+  __syncthreads();
+  return s;
+}
 
 // ---- per grid point: rk_step, the error estimate, RkDenseOutput --------------
 // KT: type of the right-hand side's values (float32 for the TF-graph models,

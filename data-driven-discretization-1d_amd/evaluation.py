@@ -133,8 +133,8 @@ def run_integrate_batch(model: model_lib.LearnedStencilModel, hparams,
                         scheme: str = 'bs3', first_seed: int = 0,
                         adaptive: Optional[bool] = None):
   """All samples of this rank together: adaptive RK23 with one controller per
-  sample (``adaptive=True``; the default for scheme='bs3' whenever the model
-  runs on the MFMA kernels), or the fixed step ``max_step`` with ``scheme``.
+  sample (``adaptive=True``; the default for scheme='bs3'), or the fixed step
+  ``max_step`` with ``scheme``.
 
   Sample i uses random_seed = first_seed + i for its forcing, like the
   reference's per-seed equations.  With torch.distributed initialised the
@@ -150,8 +150,8 @@ def run_integrate_batch(model: model_lib.LearnedStencilModel, hparams,
   if model.equation.has_time_dependent_forcing and hi > lo:
     eqs = [equations_lib.from_hparams(hparams, random_seed=s)[1] for s in seeds]
     forcing = model_lib.forcing_from_equations(eqs)
-  if adaptive is None:   # RK23's own tableau on a model the device controller supports
-    adaptive = scheme == 'bs3' and model.kernel_name.startswith('mfma')
+  if adaptive is None:   # RK23's own tableau: the reference's integrator, on the device
+    adaptive = scheme == 'bs3'
   if hi > lo:
     ds = integrate.integrate_batch(model, initial_conditions[lo:hi], warmup + times,
                                    dt=max_step, scheme=scheme, forcing=forcing,

@@ -379,27 +379,36 @@ def integrate_exact_batch(equations, times: np.ndarray = _DEFAULT_TIMES,
                           warmup: float = 0, filter_interval: float = None):
   """``integrate_exact`` (integrate.py:282-293) for many samples at once, on the
   device from start to end: what ``scripts/create_exact_data.py`` maps over
-  random seeds, for the equations whose exact method is spectral (KdV, KS).
+  random seeds.
 
   ``equations``: same type, same grid, one per sample (they differ by
-  ``random_seed``, i.e. by initial condition).  Every sample is advanced by its
-  own SciPy-identical RK23 controller over the float64 spectral right-hand side
-  (``ddd_integrate_adaptive_f64`` on a spectral model); with ``filter_interval``
-  the state passes through the smoothing filter between segments and the saved
-  trajectory once at the end, as a circulant kernel on the device
-  (``ddd_circulant_apply_f64``).  Returns a Dataset with y [sample, time, x]
-  float64 and per-sample num_evals.
+  ``random_seed``, i.e. by initial condition and forcing).  Every sample is
+  advanced by its own SciPy-identical RK23 controller
+  (``ddd_integrate_adaptive_f64``) over the equation's exact right-hand side:
+  the float64 spectral kernel for KdV / KS (``SpectralDifferentiator``), the
+  float32 WENO5 + Godunov-flux kernel with per-sample forcing for Burgers
+  (``WENODifferentiator``).  With ``filter_interval`` the state passes through
+  the smoothing filter between segments and the saved trajectory once at the
+  end, as a circulant kernel on the device (``ddd_circulant_apply_f64``).
+  Returns a Dataset with y [sample, time, x] float64 and per-sample num_evals.
   """
   exact = [eq.to_exact() for eq in equations]
   first = exact[0]
-  if first.EXACT_METHOD is not equations_lib.ExactMethod.SPECTRAL:
-    raise ValueError('integrate_exact_batch covers the spectral exact solvers (KdV, KS); '
-                     'use integrate_exact per sample for {}'.format(type(first).__name__))
   for eq in exact[1:]:
     if type(eq) is not type(first) or (eq.grid.solution_num_points, eq.grid.period) != (
         first.grid.solution_num_points, first.grid.period):
       raise ValueError('all equations must share their type and grid')
-  solver = _DeviceSolver(model_lib.SpectralModel(first, convention='fftpack'))
+  method = first.EXACT_METHOD
+  if method is equations_lib.ExactMethod.SPECTRAL:
+    device_model = model_lib.SpectralModel(first, convention='fftpack')
+  elif method is equations_lib.ExactMethod.WENO:
+    device_model = model_lib.BaselineModel(first, 3, weno=True)   # WENODifferentiator's default
+    if first.has_time_dependent_forcing:
+      device_model.set_forcing(model_lib.forcing_from_equations(exact))
+  else:
+    raise ValueError('integrate_exact_batch covers the spectral and WENO exact solvers; '
+                     'use integrate_exact per sample for {}'.format(type(first).__name__))
+  solver = _DeviceSolver(device_model)
   y0 = _lib.as_device(np.stack([eq.initial_value() for eq in exact]),
                       _lib._torch().float64)
   solution, num_evals = _solve(solver, first, y0, np.asarray(times, dtype=np.float64),

@@ -270,11 +270,12 @@ int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
  *          (a safety net SciPy does not have; <= 0 selects a default of 1000x
  *          the attempts of a run at max_step).  Rows a failed sample did not
  *          reach are NaN, as integrate.odeint pads them (integrate.py:161-167).
- * MFMA-path models (ddd_kernel_name "mfma_f32_*") and spectral models
- * (ddd_spectral_create: integrate.odeint over SpectralDifferentiator, the
- * "exact" KdV / KS solver, integrate.py:108-121, with a float64 right-hand side);
- * others return DDD_ERR_UNSUPPORTED and keep the one-sample SciPy route over
- * ddd_time_derivative. */
+ * Every model kind: MFMA-path models inside the persistent MFMA kernel; models
+ * on the generic kernel (WENODifferentiator, integrate.py:124-140: the "exact"
+ * Burgers solver; nets the MFMA path does not carry) with one workgroup per
+ * sample; spectral models (ddd_spectral_create: SpectralDifferentiator, the
+ * "exact" KdV / KS solver, integrate.py:108-121) with a float64 right-hand
+ * side. */
 int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
                                int n_times, double rtol, double atol,
                                double max_step, long long max_attempts,

@@ -72,6 +72,20 @@ for cls, n, samples, t_end in ((equations.KSEquation, 256, 256, 0.05),
                     else ds.coords['num_evals'])
   print('{} N={} {} {} {} {:.3f} {:.3e}'.format(cls.__name__, n, samples, nfev.min(), nfev.max(),
                                               wall, nfev.sum() * n / wall))
+# the WENO5 + Godunov exact Burgers solver (float32 generic kernel, per-seed forcing)
+for n, samples, t_end in ((512, 256, 0.5), (512, 2048, 0.5)):
+  eqs = [equations.BurgersEquation(n, random_seed=s) for s in range(samples)]
+  times = np.linspace(0, t_end, 3)
+  integrate.integrate_exact_batch(eqs[:8], times=times)
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  ds = integrate.integrate_exact_batch(eqs, times=times)
+  torch.cuda.synchronize()
+  wall = time.perf_counter() - t0
+  nfev = np.asarray(ds.coords['num_evals'][1] if isinstance(ds.coords['num_evals'], tuple)
+                    else ds.coords['num_evals'])
+  print('BurgersEquation(WENO) N={} {} {} {} {:.3f} {:.3e}'.format(n, samples, nfev.min(), nfev.max(),
+                                                            wall, nfev.sum() * n / wall))
 # the reference's own execution shape for one of these samples: host SciPy + HIP RHS
 eq = equations.KSEquation(256, random_seed=0)
 t0 = time.perf_counter()

@@ -284,8 +284,22 @@ def test_integrate_exact_batch_vs_reference_and_per_sample(exact):
   one = integrate.integrate_exact(eqs[1], times=times, warmup=0.02, filter_interval=0.01)
   assert int(np.asarray(_coord(one, 'num_evals'))) == int(nfev[1])
   assert rel_err(y[1], _y(one)) < 1e-9
-  with pytest.raises(ValueError):
-    integrate.integrate_exact_batch([equations.BurgersEquation(64)], times=times)
+
+
+def test_integrate_exact_batch_weno_burgers():
+  """The exact Burgers solver (WENO5 + Godunov flux, per-seed forcing) for a batch
+  on the device: every sample equals its one-sample integrate_exact run over the
+  same kernel (equal nfev, 1e-9), which the reference fixtures pin."""
+  times = np.linspace(0, 0.3, 4)
+  eqs = [equations.BurgersEquation(128, random_seed=s) for s in (3, 8, 11)]
+  ds = integrate.integrate_exact_batch(eqs, times=times, warmup=0.1)
+  y = _y(ds)
+  nfev = np.asarray(_coord(ds, 'num_evals'))
+  assert y.shape == (3, 4, 128) and np.isfinite(y).all() and np.abs(y).max() > 1e-3
+  for b in range(3):
+    one = integrate.integrate_exact(eqs[b], times=times, warmup=0.1)
+    assert int(np.asarray(_coord(one, 'num_evals'))) == int(nfev[b])
+    assert rel_err(y[b], _y(one)) < 1e-9
 
 
 def test_spectral_adaptive_large_grid_and_failure():
