@@ -14,7 +14,16 @@
 // against the installed SciPy (tests/test_cpu_oracle.py).  Python's min / max
 // are restated with their NaN behaviour (min(a, b) is a unless b < a).
 #pragma once
+#ifdef DDD_RK23_HOST
+// The same statements compiled by g++ for the CPU test tier
+// (oracle/rk23_host.cpp, tests/test_cpu_rk23_source.py): this very header,
+// driven over a Python right-hand side, against the installed SciPy.
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 namespace ddd {
 namespace rk23 {
@@ -108,6 +117,7 @@ struct Control {
   }
 };
 
+#ifndef DDD_RK23_HOST
 // Sum over a 256-thread workgroup, identical (bitwise) on every thread: wave
 // butterflies, then the four wave totals in a fixed order.  `red`: 4 doubles of LDS.
 __device__ __forceinline__ double block_sum256(double v, double* red) {
@@ -118,6 +128,7 @@ __device__ __forceinline__ double block_sum256(double v, double* red) {
   __syncthreads();
   return s;
 }
+#endif
 
 // ---- per grid point: rk_step, the error estimate, RkDenseOutput --------------
 // KT: type of the right-hand side's values (float32 for the TF-graph models,
