@@ -551,6 +551,19 @@ def _differentiator_config(args):
     elapsed += time.perf_counter() - t0
     calls += 500
   us = elapsed / calls * 1e6
+  # one whole one-sample solve as integrate.odeint does it: SciPy's RK23 for t in
+  # [0, 1] (302 evaluations) on the device in one launch, and as the reference's
+  # host loop over the same differentiator
+  times = np.linspace(0.0, 1.0, 11)
+  integrate.odeint(y, diff, times)
+  t0 = time.perf_counter()
+  _, nfev = integrate.odeint(y, diff, times)
+  odeint_device_ms = (time.perf_counter() - t0) * 1e3
+  integrate.DEVICE_ODEINT = False
+  t0 = time.perf_counter()
+  integrate.odeint(y, diff, times)
+  odeint_host_ms = (time.perf_counter() - t0) * 1e3
+  integrate.DEVICE_ODEINT = True
   n = eq.grid.solution_num_points
   flops = 2.0 * diff.model.fma_per_point * n
   result = {
@@ -561,6 +574,10 @@ def _differentiator_config(args):
       'bound': 'latency', 'fp32_tflops': flops / (us * 1e-6) / 1e12,
       'frac': flops / (us * 1e-6) / 1e12 / PEAK_FP32_TFLOPS,
       'reference_ms_per_evaluation': [2.0, 4.3], 'finite': bool(np.isfinite(out).all()),
+      'odeint_one_sample': {
+          'workload': 'integrate.odeint(y0, differentiator, linspace(0, 1, 11)): RK23, '
+                      '{} evaluations'.format(nfev),
+          'device_ms': odeint_device_ms, 'host_loop_ms': odeint_host_ms},
   }
   diff.model.close()
   return 'differentiator_b1', result

@@ -5,7 +5,8 @@ Mirror of ``pde_superresolution/integrate.py`` for the learned-stencil path:
   Differentiator                 integrate.py:40-45
   SavedModelDifferentiator       integrate.py:48-71   (HIP model instead of a TF session)
   PolynomialDifferentiator       integrate.py:74-105
-  odeint                         integrate.py:143-169 (SciPy RK23, max_step 0.01)
+  odeint                         integrate.py:143-169 (SciPy RK23, max_step 0.01; over a HIP
+                                 differentiator the same controller runs on the device)
   integrate_exact_batch          integrate_exact for a batch, entirely on the device
   SpectralDifferentiator         integrate.py:108-121 (float64 circulant kernel)
   WENODifferentiator             integrate.py:124-140
@@ -84,6 +85,11 @@ class _HipDifferentiator(Differentiator):
     self.model = device_model
     self._torch = _lib.require_gpu()
 
+  @property
+  def device_model(self):
+    """The model whose on-device RK23 equals solve_ivp over this differentiator."""
+    return self.model
+
   def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
     y32 = np.ascontiguousarray(np.asarray(y, dtype=np.float32)[np.newaxis, :])
     out = self.model.time_derivative(y32, t)
@@ -140,6 +146,12 @@ class PolynomialDifferentiator(_HipDifferentiator):
       model.set_forcing_from_equation(batch=1)
     super(PolynomialDifferentiator, self).__init__(model)
 
+  @property
+  def device_model(self):
+    if self._spectral and self.equation.has_time_dependent_forcing:
+      return None   # finalize_time_derivative runs on the host
+    return self.model
+
   def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
     if not self._spectral:
       return super(PolynomialDifferentiator, self).__call__(t, y)
@@ -172,6 +184,12 @@ class SpectralDifferentiator(Differentiator):
     self.equation = equation
     self.model = model_lib.SpectralModel(equation, convention='fftpack')
     self._torch = _lib.require_gpu()
+
+  @property
+  def device_model(self):
+    if self.equation.has_time_dependent_forcing:
+      return None   # finalize_time_derivative (the forcing) runs on the host in float64
+    return self.model
 
   def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
     y64 = np.ascontiguousarray(np.asarray(y, dtype=np.float64)[np.newaxis, :])
@@ -222,6 +240,13 @@ def exact_differentiator(equation) -> Differentiator:
 # batched on-device RK23 of ddd_integrate_adaptive_f64 + the circulant filter
 # kernel, whole batches, nothing leaves the GPU between segments).
 # ---------------------------------------------------------------------------
+# One-sample solves over a HIP differentiator run SciPy's RK23 on the device
+# (ddd_integrate_adaptive_f64 with batch 1: same evaluations, same trajectory,
+# one launch instead of one host round trip per evaluation).  False restores
+# the literal reference shape: SciPy on the host calling the differentiator.
+DEVICE_ODEINT = True
+
+
 class _HostSolver(object):
   """scipy.integrate.solve_ivp(max_step=0.01) over a Differentiator: one sample,
   state [x], trajectories [time, x] (integrate.py:143-169)."""
@@ -231,6 +256,12 @@ class _HostSolver(object):
     self.method = method
 
   def solve(self, y0, times):
+    device_model = getattr(self.differentiator, 'device_model', None)
+    if DEVICE_ODEINT and self.method == 'RK23' and device_model is not None:
+      y, nfev, _ = device_model.integrate_adaptive(
+          np.asarray(y0, dtype=np.float64)[np.newaxis], np.asarray(times, dtype=np.float64),
+          max_step=0.01)
+      return y[:, 0].cpu().numpy(), int(nfev[0])
     import scipy.integrate
     logging.info('solve_ivp from %s to %s', times[0], times[-1])
     sol = scipy.integrate.solve_ivp(self.differentiator, (times[0], times[-1]), y0,

@@ -254,12 +254,13 @@ def test_smoothing_filter_on_device_vs_reference(exact):
   assert rel_err(got, duckarray.smoothing_filter(stacked, order=2)) < 1e-12
 
 
-def test_integrate_exact_batch_vs_reference_and_per_sample(exact):
+def test_integrate_exact_batch_vs_reference_and_per_sample(exact, monkeypatch):
   """integrate_exact_batch: every sample with its own RK23 controller over the
   float64 spectral right-hand side, warm-up and periodic filtering on the device.
   The sample the reference fixture was generated for reproduces the reference's
   trajectory AND its evaluation count; every sample equals the one-sample host
   SciPy run over the same kernel (nfev equal, 1e-9)."""
+  monkeypatch.setattr(integrate, 'DEVICE_ODEINT', False)   # per-sample runs: SciPy on the host
   times = np.linspace(0, 0.1, 3)
   eqs = [equations.KdVEquation(64, random_seed=s) for s in (1, 5, 9, 12)]
   ds = integrate.integrate_exact_batch(eqs, times=times, warmup=0.05)
@@ -286,10 +287,11 @@ def test_integrate_exact_batch_vs_reference_and_per_sample(exact):
   assert rel_err(y[1], _y(one)) < 1e-9
 
 
-def test_integrate_exact_batch_weno_burgers():
+def test_integrate_exact_batch_weno_burgers(monkeypatch):
   """The exact Burgers solver (WENO5 + Godunov flux, per-seed forcing) for a batch
   on the device: every sample equals its one-sample integrate_exact run over the
   same kernel (equal nfev, 1e-9), which the reference fixtures pin."""
+  monkeypatch.setattr(integrate, 'DEVICE_ODEINT', False)   # per-sample runs: SciPy on the host
   times = np.linspace(0, 0.3, 4)
   eqs = [equations.BurgersEquation(128, random_seed=s) for s in (3, 8, 11)]
   ds = integrate.integrate_exact_batch(eqs, times=times, warmup=0.1)
@@ -302,9 +304,10 @@ def test_integrate_exact_batch_weno_burgers():
     assert rel_err(y[b], _y(one)) < 1e-9
 
 
-def test_spectral_adaptive_large_grid_and_failure():
+def test_spectral_adaptive_large_grid_and_failure(monkeypatch):
   """N = 512 (two grid points per thread) and N = 2048 (eight); a sample that
   blows up stops with status -1 and NaN rows while its neighbours finish."""
+  monkeypatch.setattr(integrate, 'DEVICE_ODEINT', False)
   for n, horizon in ((512, 2e-3), (2048, 2e-5)):
     eq = equations.KdVEquation(n, random_seed=3)
     model = model_lib.SpectralModel(eq)

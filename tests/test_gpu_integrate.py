@@ -276,3 +276,31 @@ def test_mean_conservation_long_run():
   drift = np.abs(out[0].mean(axis=1) - y0.mean(axis=1)).max()
   assert np.isfinite(out).all()
   assert drift < 1e-5
+
+
+def test_odeint_on_the_device_equals_scipy_on_the_host(monkeypatch):
+  """integrate.odeint over a HIP differentiator runs SciPy's RK23 on the device
+  (one launch per solve); with DEVICE_ODEINT = False it is SciPy on the host
+  calling the differentiator once per evaluation (the reference's shape).  Same
+  evaluation count, same trajectory, for every differentiator kind."""
+  cases = []
+  model = make_model('burgers', True, num_points=64)
+  cases.append((integrate.SavedModelDifferentiator(None, model.equation, model=model),
+                model.equation.initial_value() + 0.3 * np.sin(model.equation.grid.solution_x)))
+  eq = equations.ConservativeKdVEquation(64, resample_factor=4, random_seed=2)
+  cases.append((integrate.PolynomialDifferentiator(eq, 1), eq.initial_value()))
+  eq = equations.GodunovBurgersEquation(96, random_seed=4)
+  cases.append((integrate.WENODifferentiator(eq), 0.5 * np.sin(eq.grid.solution_x)))
+  eq = equations.KdVEquation(64, random_seed=6)
+  cases.append((integrate.SpectralDifferentiator(eq), eq.initial_value()))
+  times = np.array([0.0, 0.013, 0.1, 0.2])
+  for diff, y0 in cases:
+    monkeypatch.setattr(integrate, 'DEVICE_ODEINT', True)
+    dev, dev_nfev = integrate.odeint(y0, diff, times)
+    monkeypatch.setattr(integrate, 'DEVICE_ODEINT', False)
+    host, host_nfev = integrate.odeint(y0, diff, times)
+    assert dev_nfev == host_nfev, (type(diff).__name__, dev_nfev, host_nfev)
+    assert dev.shape == host.shape and rel_err(dev, host) < 1e-9, type(diff).__name__
+  # forced spectral Burgers keeps the host loop (its forcing is applied on the host)
+  eq = equations.BurgersEquation(64, random_seed=1)
+  assert integrate.SpectralDifferentiator(eq).device_model is None
