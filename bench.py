@@ -560,10 +560,12 @@ def _differentiator_config(args):
   _, nfev = integrate.odeint(y, diff, times)
   odeint_device_ms = (time.perf_counter() - t0) * 1e3
   integrate.DEVICE_ODEINT = False
-  t0 = time.perf_counter()
-  integrate.odeint(y, diff, times)
-  odeint_host_ms = (time.perf_counter() - t0) * 1e3
-  integrate.DEVICE_ODEINT = True
+  try:
+    t0 = time.perf_counter()
+    integrate.odeint(y, diff, times)
+    odeint_host_ms = (time.perf_counter() - t0) * 1e3
+  finally:
+    integrate.DEVICE_ODEINT = True
   n = eq.grid.solution_num_points
   flops = 2.0 * diff.model.fma_per_point * n
   result = {

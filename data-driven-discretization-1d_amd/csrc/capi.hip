@@ -194,6 +194,7 @@ struct ddd_model {
   // output times of ddd_integrate_adaptive_f64
   double* d_times = nullptr;
   size_t times_capacity = 0;
+  std::vector<double> h_times;       // staging copy that outlives the asynchronous upload
   // scratch for the per-substep launch mode
   float* d_scratch = nullptr;
   size_t scratch_floats = 0;
@@ -1429,14 +1430,18 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   if (batch == 0) return DDD_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   if (m->times_capacity < (size_t)n_times) {
-    DDD_HIP(hipStreamSynchronize(stream));   // an earlier launch may still read the old table
     free_dev(m->d_times);
     m->d_times = nullptr;
     m->times_capacity = 0;
     DDD_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_times), (size_t)n_times * sizeof(double)));
     m->times_capacity = (size_t)n_times;
   }
-  DDD_HIP(hipMemcpyAsync(m->d_times, times, (size_t)n_times * sizeof(double),
+  // (the caller's array may be gone before the copy runs: upload from a copy the
+  // model owns; an earlier launch that still reads d_times is ordered before it
+  // on the same stream)
+  DDD_HIP(hipStreamSynchronize(stream));
+  m->h_times.assign(times, times + n_times);
+  DDD_HIP(hipMemcpyAsync(m->d_times, m->h_times.data(), (size_t)n_times * sizeof(double),
                          hipMemcpyHostToDevice, stream));
   ddd::AdaptiveArgs a{};
   a.times = m->d_times; a.n_times = n_times;
