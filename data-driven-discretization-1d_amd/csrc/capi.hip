@@ -491,8 +491,8 @@ void decide_mfma(ddd_model* m) {
     // no projection) run on the run-time-parameterised MFMA kernels
     if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2) wide = true;
     if (dp.C_out > ddd::kChMax) wide = true;
-    if (dp.F != ddd::mfma::kF) no("filter_size != 32");
-    if (dp.K != ddd::mfma::kKW) no("kernel_size != 5");
+    if (dp.F != ddd::mfma::kF) no("filter_size > 32");        // (smaller ones arrive zero-padded)
+    if (dp.K != ddd::mfma::kKW) no("kernel_size > 5");
     if (dp.L < 2) no("fewer than 2 conv layers");
     if (dp.C_out > ddd::kChWide) no("more than 24 output channels");
   }
@@ -882,6 +882,46 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   }
 
   std::vector<float> wv(weights, weights + n_weights);
+  // Smaller towers ride the 5-tap x 32-channel MFMA layers EXACTLY, embedded
+  // with zero weights: a K-tap kernel (K < 5) is the 5-tap kernel whose outer
+  // taps are zero (tap k of K sits at offset k - ceil((K-1)/2), the alignment of
+  // layers.pad_periodic(center=True), layers.py:76-79), F < 32 filters are 32
+  // filters whose extra rows / columns / biases are zero.  fma(0, x, acc) == acc
+  // for every finite x, and a padded channel is multiplied by zero weights in the
+  // next layer whatever the activation makes of its 0, so the finite results are
+  // bit-identical to the unpadded evaluation order-for-order; the matrix work
+  // grows by 5/K and (32/F)^2, still an order of magnitude ahead of the generic
+  // kernel.  (Algorithmic FLOPs -- ddd_fma_per_point -- keep counting the true net.)
+  if (dp.L >= 2 && dp.K <= ddd::mfma::kKW && dp.F <= ddd::mfma::kF &&
+      (dp.K != ddd::mfma::kKW || dp.F != ddd::mfma::kF)) {
+    const int k5 = ddd::mfma::kKW, f32 = ddd::mfma::kF;
+    const int shift = (k5 - 1) / 2 - dp.K / 2;   // ceil((5-1)/2) - ceil((K-1)/2)
+    std::vector<float> padded;
+    int w_off[ddd::kMaxLayers], b_off[ddd::kMaxLayers], cin[ddd::kMaxLayers], cout[ddd::kMaxLayers];
+    for (int l = 0; l < dp.L; ++l) {
+      cin[l] = l == 0 ? 1 : f32;
+      cout[l] = l == dp.L - 1 ? c_out : f32;
+      w_off[l] = (int)padded.size();
+      padded.resize(padded.size() + (size_t)k5 * cin[l] * cout[l], 0.0f);
+      b_off[l] = (int)padded.size();
+      padded.resize(padded.size() + (size_t)cout[l], 0.0f);
+      const float* w = wv.data() + dp.w_off[l];
+      const float* b = wv.data() + dp.b_off[l];
+      for (int k = 0; k < dp.K; ++k)
+        for (int ci = 0; ci < dp.cin[l]; ++ci)
+          for (int co = 0; co < dp.cout[l]; ++co)
+            padded[(size_t)w_off[l] + ((size_t)(k + shift) * cin[l] + ci) * cout[l] + co] =
+                w[((size_t)k * dp.cin[l] + ci) * dp.cout[l] + co];
+      for (int co = 0; co < dp.cout[l]; ++co) padded[(size_t)b_off[l] + co] = b[co];
+    }
+    for (int l = 0; l < dp.L; ++l) {
+      dp.w_off[l] = w_off[l]; dp.b_off[l] = b_off[l]; dp.cin[l] = cin[l]; dp.cout[l] = cout[l];
+    }
+    dp.K = k5;
+    dp.F = f32;
+    wv.swap(padded);
+    weights = wv.data();
+  }
   rc = upload(wv, &m->d_weights);
   dp.weights = m->d_weights;
   if (!rc && projected) {

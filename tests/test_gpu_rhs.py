@@ -222,12 +222,34 @@ def test_accuracy_order_zero_with_three_derivatives_runs_on_the_wide_kernels():
 
 
 @pytest.mark.parametrize('overrides', [
-    dict(num_layers=1), dict(filter_size=16), dict(kernel_size=3),
-    dict(kernel_size=4), dict(coefficient_grid_min_size=13),
-    dict(num_layers=0),
+    dict(filter_size=16), dict(kernel_size=3), dict(kernel_size=4), dict(kernel_size=1),
+    dict(filter_size=8, kernel_size=2, num_layers=4, nonlinearity='softplus'),
+    dict(filter_size=24, kernel_size=3, coefficient_grid_min_size=9),
+])
+def test_smaller_towers_embedded_in_the_mfma_layers(overrides):
+  """kernel_size < 5 and filter_size < 32 ride the 5-tap x 32-channel MFMA layers
+  with zero-padded weights (capi.hip: ddd_model_create): exact embedding, so the
+  oracle evaluating the TRUE net is matched at the usual tolerance."""
+  for equation, conservative in (('burgers', True), ('ks', False)):
+    model = make_model(equation, conservative, num_points=64, **overrides)
+    assert model.kernel_name == 'mfma_f32_r64', (overrides, model.kernel_name)
+    y0 = random_phase_ic(model.equation, 5)
+    forcing = batch_forcing(5)
+    model.set_forcing(forcing)
+    _check_all_views(model, y0, 0.2, forcing, None)
+    dt = 1e-5
+    got = model.integrate_fixed(y0, 10, dt=dt, save_every=10).cpu().numpy()
+    want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 10, 10, y0,
+                                  forcing=forcing if equation == 'burgers' else None)
+    assert rel_err(got, want) < TOL, (equation, overrides)
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=1), dict(filter_size=64), dict(kernel_size=7),
+    dict(coefficient_grid_min_size=13), dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
-  """Configurations the MFMA path does not cover (other filter / kernel sizes,
+  """Configurations the MFMA path does not cover (more than 32 filters or 5 taps,
   one-layer nets, stencils wider than 12) run on the generic kernel (never on
   the CPU)."""
   conservative = not overrides.get('ensure_unbiased_coefficients', False)
