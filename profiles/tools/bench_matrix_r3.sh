@@ -14,6 +14,11 @@ python bench.py $common --hparams '{"model_target": "time_derivative"}' > $out/r
 python bench.py $common --equation ks --hparams '{"coefficient_grid_min_size": 9}' > $out/wide_ks_cgms9.json 2>>$out/err.log
 python bench.py $common --equation ks --hparams '{"polynomial_accuracy_order": 0}' > $out/wide_ks_pao0.json 2>>$out/err.log
 python bench.py $common --equation ks --hparams '{"coefficient_grid_min_size": 9}' --kernel generic --batch 1024 > $out/generic_ks_cgms9.json 2>>$out/err.log
+# smaller towers embedded with zero weights in the 5-tap x 32-channel MFMA layers; larger ones on the generic kernel
+python bench.py $common --hparams '{"kernel_size": 3}' > $out/embedded_kernel3.json 2>>$out/err.log
+python bench.py $common --hparams '{"filter_size": 16}' > $out/embedded_filter16.json 2>>$out/err.log
+python bench.py $common --hparams '{"kernel_size": 7}' --batch 1024 --steps 50 > $out/generic_kernel7.json 2>>$out/err.log
+python bench.py $common --hparams '{"filter_size": 64}' --batch 1024 --steps 50 > $out/generic_filter64.json 2>>$out/err.log
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob('gpurun_out/r3m/*.json')):
