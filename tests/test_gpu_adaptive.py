@@ -304,3 +304,16 @@ def test_integrate_batch_adaptive_dataset():
   evals = np.asarray(integrate._dataset_coord(ds, 'num_evals'))
   # 11 steps: the first one is select_initial_step's, shorter than max_step
   assert evals.shape == (5,) and (evals == 2 + 3 * 11).all()
+
+
+def test_start_time_is_not_zero_and_single_sample_batches():
+  """t_eval starting at t0 = 1.5 (the forcing is evaluated at absolute times), a
+  batch of one, and a batch whose last workgroup is half empty (N = 32: two
+  samples per wavefront, three samples)."""
+  model = make_model('burgers', True, num_points=32, resample_factor=4)
+  times = np.array([1.5, 1.52, 1.61, 1.7])
+  for batch in (1, 3):
+    y0 = (0.4 * random_phase_ic(model.equation, batch, seed0=77)).astype(np.float64)
+    nfev, status, bad, worst = _check(model, y0, times, batch_forcing(batch, seed0=5),
+                                      hip_samples=range(batch))
+    assert not bad and (status == 0).all() and worst < TOL
