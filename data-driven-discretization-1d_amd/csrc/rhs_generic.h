@@ -22,7 +22,20 @@ struct Carve {
   float* u;      // [N]
   float* flux;   // [N]
   float* dy;     // [N]
+  float* wl;     // one layer's weights [K][Cin][Cout4] + bias [Cout4], or null (does not fit)
 };
+
+// Floats of the per-layer weight stage: the largest layer with its output
+// channels padded to a multiple of four (the conv loop reads four per ds_read_b128).
+__host__ __device__ inline size_t weight_stage_floats(const DevParams& p) {
+  size_t most = 0;
+  for (int l = 0; l < p.L; ++l) {
+    const size_t c4 = (size_t)((p.cout[l] + 3) & ~3);
+    const size_t need = (size_t)p.K * p.cin[l] * c4 + c4;
+    most = need > most ? need : most;
+  }
+  return most;
+}
 
 __host__ __device__ inline int max_channels(const DevParams& p) {
   int c = 1;
@@ -32,17 +45,34 @@ __host__ __device__ inline int max_channels(const DevParams& p) {
 
 // Bytes of dynamic LDS for `state_bytes`-wide integration state (0 for the
 // substep kernel).
-__host__ __device__ inline size_t lds_bytes(const DevParams& p, int state_bytes) {
+// (`staged`: with the per-layer weight stage; the stage is dropped when the
+// total would not fit the CU's 160 KiB)
+__host__ __device__ inline size_t lds_bytes_with(const DevParams& p, int state_bytes,
+                                                bool staged) {
   const size_t n = (size_t)p.N;
   size_t floats = 3 * n;
   if (!p.fixed) floats += 2 * n * (size_t)max_channels(p);
+  floats = (floats + 3) & ~(size_t)3;
+  if (!p.fixed && staged) floats += weight_stage_floats(p);
   size_t bytes = floats * sizeof(float);
   bytes = (bytes + 15) & ~(size_t)15;
   if (state_bytes) bytes += 2 * n * (size_t)state_bytes + n * sizeof(float);
   return bytes;
 }
+// adaptive_kernel's extra state behind the front part: 2 float64 + 3 float32 per point
+__host__ __device__ inline size_t adaptive_extra_bytes(const DevParams& p) {
+  return (size_t)p.N * (2 * sizeof(double) + 3 * sizeof(float));
+}
+__host__ __device__ inline bool weights_staged(const DevParams& p, int state_bytes,
+                                               size_t extra_bytes = 0) {
+  return !p.fixed && lds_bytes_with(p, state_bytes, true) + extra_bytes <= 160 * 1024;
+}
+__host__ __device__ inline size_t lds_bytes(const DevParams& p, int state_bytes,
+                                            size_t extra_bytes = 0) {
+  return lds_bytes_with(p, state_bytes, weights_staged(p, state_bytes, extra_bytes));
+}
 
-__device__ __forceinline__ Carve carve(const DevParams& p, float* base) {
+__device__ __forceinline__ Carve carve(const DevParams& p, float* base, bool staged) {
   Carve c;
   const int cm = p.fixed ? 0 : max_channels(p);
   c.act_a = base;
@@ -50,6 +80,8 @@ __device__ __forceinline__ Carve carve(const DevParams& p, float* base) {
   c.u = base + 2 * (size_t)p.N * cm;
   c.flux = c.u + p.N;
   c.dy = c.flux + p.N;
+  const size_t front = ((size_t)(3 * p.N) + 2 * (size_t)p.N * cm + 3) & ~(size_t)3;
+  c.wl = (!p.fixed && staged) ? base + front : nullptr;
   return c;
 }
 
@@ -76,6 +108,48 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
       const float* __restrict__ b = p.weights + p.b_off[l];
       const int act = (l < p.L - 1) ? p.act : ACT_NONE;
       const int left = p.K / 2;   // ceil((K-1)/2): layers.pad_periodic(center=True)
+      if (c.wl != nullptr) {
+        // Fast form: the layer's weights staged in LDS with the output channels
+        // padded to fours; a thread owns 2 positions x 4 output channels and reads,
+        // per (tap, input channel), one ds_read_b128 of weights and two
+        // activations for eight FMAs.  Same accumulation order as the plain
+        // form below (tap-major, then input channel): same bits.
+        const int c4 = (cout + 3) & ~3;
+        for (int i = tid; i < p.K * cin * c4; i += kThreads) {
+          const int col = i % c4, kc = i / c4;
+          c.wl[i] = col < cout ? w[(size_t)kc * cout + col] : 0.0f;
+        }
+        float* bl = c.wl + (size_t)p.K * cin * c4;
+        for (int i = tid; i < c4; i += kThreads) bl[i] = i < cout ? b[i] : 0.0f;
+        __syncthreads();
+        const int quads = c4 / 4, pairs = (n + 1) / 2;
+        for (int item = tid; item < pairs * quads; item += kThreads) {
+          const int q = item % quads, pp = item / quads;
+          const int pos0 = 2 * pp, pos1 = (2 * pp + 1 < n) ? 2 * pp + 1 : 2 * pp;
+          float a0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          for (int k = 0; k < p.K; ++k) {
+            const float* __restrict__ r0 = cur + (size_t)wrap(pos0 + k - left, n) * cin;
+            const float* __restrict__ r1 = cur + (size_t)wrap(pos1 + k - left, n) * cin;
+            const float4* __restrict__ wk =
+                reinterpret_cast<const float4*>(c.wl + (size_t)k * cin * c4) + q;
+            for (int ci = 0; ci < cin; ++ci) {
+              const float4 w4 = wk[(size_t)ci * quads];
+              const float x0 = r0[ci], x1 = r1[ci];
+              a0[0] = fmaf(x0, w4.x, a0[0]); a0[1] = fmaf(x0, w4.y, a0[1]);
+              a0[2] = fmaf(x0, w4.z, a0[2]); a0[3] = fmaf(x0, w4.w, a0[3]);
+              a1[0] = fmaf(x1, w4.x, a1[0]); a1[1] = fmaf(x1, w4.y, a1[1]);
+              a1[2] = fmaf(x1, w4.z, a1[2]); a1[3] = fmaf(x1, w4.w, a1[3]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = 4 * q + r;
+            if (co >= cout) continue;
+            nxt[(size_t)pos0 * cout + co] = apply_activation(a0[r] + bl[co], act);
+            if (pos1 != pos0) nxt[(size_t)pos1 * cout + co] = apply_activation(a1[r] + bl[co], act);
+          }
+        }
+      } else
       for (int idx = tid; idx < n * cout; idx += kThreads) {
         const int pos = idx / cout;
         const int co = idx - pos * cout;
@@ -175,7 +249,7 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
 
 __global__ __launch_bounds__(kThreads) void substep_kernel(DevParams p, SubstepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Carve c = carve(p, smem);
+  const Carve c = carve(p, smem, weights_staged(p, 0));
   const long sample = blockIdx.x;
   const size_t off = (size_t)sample * p.N;
   for (int i = threadIdx.x; i < p.N; i += kThreads) c.u[i] = a.y_in[off + i];
@@ -197,8 +271,9 @@ __global__ __launch_bounds__(kThreads) void substep_kernel(DevParams p, SubstepA
 template <typename ST>
 __global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, IntegrateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Carve c = carve(p, smem);
-  const size_t front = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  const bool staged = weights_staged(p, (int)sizeof(ST));
+  const Carve c = carve(p, smem, staged);
+  const size_t front = (lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15;
   ST* y = reinterpret_cast<ST*>(reinterpret_cast<char*>(smem) + front);
   ST* ynew = y + p.N;
   float* kprev = reinterpret_cast<float*>(ynew + p.N);
@@ -241,10 +316,11 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, Integr
   }
 }
 
-// Extra dynamic LDS of adaptive_kernel behind lds_bytes(p, 0): y, y_new
-// (float64) and three stage derivatives (float32) per grid point.
+// Dynamic LDS of adaptive_kernel: the front part + y, y_new (float64) and three
+// stage derivatives (float32) per grid point.
 __host__ __device__ inline size_t adaptive_lds_bytes(const DevParams& p) {
-  return ((lds_bytes(p, 0) + 15) & ~(size_t)15) + (size_t)p.N * (2 * sizeof(double) + 3 * sizeof(float));
+  const bool staged = weights_staged(p, 0, adaptive_extra_bytes(p) + 16);
+  return ((lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15) + adaptive_extra_bytes(p);
 }
 
 // integrate.odeint (integrate.py:143-169) for a batch of samples on the generic
@@ -256,8 +332,9 @@ __host__ __device__ inline size_t adaptive_lds_bytes(const DevParams& p) {
 __global__ __launch_bounds__(kThreads) void adaptive_kernel(DevParams p, AdaptiveArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ double red[4];
-  const Carve c = carve(p, smem);
-  const size_t front = (lds_bytes(p, 0) + 15) & ~(size_t)15;
+  const bool staged = weights_staged(p, 0, adaptive_extra_bytes(p) + 16);
+  const Carve c = carve(p, smem, staged);
+  const size_t front = (lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15;
   double* y = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + front);
   double* y_new = y + p.N;
   float* k0 = reinterpret_cast<float*>(y_new + p.N);
