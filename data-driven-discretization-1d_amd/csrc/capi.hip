@@ -45,6 +45,7 @@ struct DebugOptions {
   int substep_parts = 0; // A/B: sample slabs advanced side by side in the per-substep modes (0: auto)
   int ablate = 0;        // skips kernel phases: WRONG RESULTS (run-time-parameterised kernels)
   unsigned long long trace_ptr = 0;   // device buffer for s_memtime phase stamps
+  unsigned long long walk_trace_ptr = 0;   // device buffer for the wave-lifetime stamps of the substep walk
 };
 #ifdef DDD_PROBES
 DebugOptions g_debug;
@@ -297,6 +298,16 @@ int upload_padded_tables(ddd_model* m, const float* nullspace, const float* bias
   return DDD_OK;
 }
 
+// [rows][64] -> the storage order of rhs_mfma.h load_rows4: four rows to a float4 per
+// lane, rows zero-padded to a multiple of four.
+std::vector<float> quad_rows(const float* rows64, int rows) {
+  std::vector<float> out((size_t)ddd::mfma::padded_rows4(rows) * 64, 0.0f);
+  for (int s = 0; s < rows; ++s)
+    for (int lane = 0; lane < 64; ++lane)
+      out[((size_t)(s >> 2) * 64 + lane) * 4 + (s & 3)] = rows64[(size_t)s * 64 + lane];
+  return out;
+}
+
 // Reorder conv weights into MFMA A-operand order (rhs_mfma.h).
 int pack_mfma_weights(ddd_model* m, const float* weights) {
   const ddd::DevParams& dp = m->dp;
@@ -311,7 +322,7 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
         const int k = 2 * s + (lane >> 5), ch = lane & 31;
         packed[s * 64 + lane] = k < 5 ? w[k * 32 + ch] : b[ch];
       }
-    int rc = upload(packed, &m->d_w_input);
+    int rc = upload(quad_rows(packed.data(), ddd::mfma::kInSteps), &m->d_w_input);
     if (rc) return rc;
     m->dp.w_input = m->d_w_input;
   }
@@ -331,7 +342,13 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
       for (int lane = 0; lane < 64; ++lane)
         dst[80 * 64 + lane] = (lane >> 5) == 0 ? b[lane & 31] : 0.0f;
     }
-    int rc = upload(packed, &m->d_w_hidden);
+    std::vector<float> stored;   // every hidden layer padded on its own (load_hidden)
+    for (int h = 0; h < hidden; ++h) {
+      const std::vector<float> q =
+          quad_rows(packed.data() + (size_t)h * ddd::mfma::kHidSteps * 64, ddd::mfma::kHidSteps);
+      stored.insert(stored.end(), q.begin(), q.end());
+    }
+    int rc = upload(stored, &m->d_w_hidden);
     if (rc) return rc;
     m->dp.w_hidden = m->d_w_hidden;
   }
@@ -462,7 +479,9 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
     m->spec_folded = can_fold && groups_folded <= groups_plain;
     m->dp.fin4_groups = m->spec_folded ? groups_folded : groups_plain;
     if (!m->wide) {   // (the specialised kernels never serve a wide model)
-      rc = upload(pack4(m->dp.fin4_groups, m->spec_folded, true), &m->d_w_final4);
+      rc = upload(quad_rows(pack4(m->dp.fin4_groups, m->spec_folded, true).data(),
+                            ddd::mfma::fin4_regs(4)),
+                  &m->d_w_final4);
       if (rc) return rc;
       m->dp.w_final4 = m->d_w_final4;
     }
@@ -1090,6 +1109,7 @@ int ddd_clear_forcing(ddd_model* m) {
   m->d_frc = nullptr; m->d_sp = nullptr; m->d_trig = nullptr; m->d_runs = nullptr;
   m->dp.trig = nullptr; m->dp.runs = nullptr;
   m->dp.forced = 0; m->dp.P = 0; m->dp.n_k = 0; m->dp.forcing_batch = 0;
+  m->dp.inv_P = 0.0f; m->dp.inv_nk = 1.0f;
   m->dp.frc = nullptr; m->dp.sp = nullptr;
   return DDD_OK;
 }
@@ -1174,6 +1194,8 @@ int ddd_set_forcing(ddd_model* m, int batch, int nparams, const float* amplitude
   m->dp.forced = 1;
   m->dp.P = nparams;
   m->dp.n_k = n_k;
+  m->dp.inv_P = 1.0f / (float)nparams;
+  m->dp.inv_nk = 1.0f / (float)std::max(n_k, 1);
   m->dp.forcing_batch = batch;
   return DDD_OK;
 }
@@ -1317,6 +1339,9 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   for (int i = 0; i < kMaxParts; ++i) half_off[i] = (size_t)slab_first[i] * m->dp.N;
   const float* y = y0;
   size_t snap = 0;
+#ifdef DDD_PROBES
+  int walk_launch = 0;
+#endif
   for (int step = 0; step < n_steps; ++step) {
     const double t = t0 + (double)step * dt;
     const bool saving = (step + 1) % save_every == 0;
@@ -1373,6 +1398,10 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
           a.c2 = tab.b[s] * h;
           a.acc_out = ynew + off;
         }
+#ifdef DDD_PROBES
+        a.trace = reinterpret_cast<unsigned long long*>(g_debug.walk_trace_ptr);
+        a.trace_row0 = walk_launch++ * ddd::kWalkTraceRows;
+#endif
         rc = launch_substep(m, a, lanes[hf], slab_first[hf], halves);
         if (rc) return rc;
       }
@@ -1722,7 +1751,7 @@ int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0;
 #ifdef DDD_PROBES
 // Profiling / A-B switches (not part of the product API; every change is
 // logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
-// no_stream, prio_split, stagger, substep_parts, ablate, trace_ptr; "reset" puts
+// no_stream, prio_split, stagger, substep_parts, ablate, trace_ptr, walk_trace_ptr; "reset" puts
 // every switch back to its default (the switches are process-global).
 int ddd_debug_set_option(const char* name, long long value) {
   if (name == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "name is NULL");
@@ -1736,6 +1765,7 @@ int ddd_debug_set_option(const char* name, long long value) {
   else if (key == "reset") g_debug = DebugOptions{};   // every switch back to its default
   else if (key == "ablate") g_debug.ablate = (int)value;
   else if (key == "trace_ptr") g_debug.trace_ptr = (unsigned long long)value;
+  else if (key == "walk_trace_ptr") g_debug.walk_trace_ptr = (unsigned long long)value;
   else return fail(DDD_ERR_INVALID_ARGUMENT, "unknown debug option '%s'", name);
   fprintf(stderr, "libddd1d: debug option %s = %lld%s\n", name, value,
           key == "ablate" && value != 0 ? " (kernel phases skipped: results are WRONG)" : "");

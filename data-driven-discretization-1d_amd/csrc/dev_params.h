@@ -15,6 +15,7 @@ constexpr int kGMax = 8;      // widest stencil of the default MFMA kernels (and
 constexpr int kGWide = 12;
 constexpr int kChMax = 16, kChWide = 24;
 constexpr int kTraceSlots = 256;
+constexpr int kWalkTraceRows = 2048;   // rows per launch of the substep-walk trace (probe library)
 constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
 
 // Equation ids: include/ddd1d.h enum ddd_equation.
@@ -76,6 +77,8 @@ struct DevParams {
   int fin4_groups;            // groups of w_final4
   // per-sample forcing
   int forced, P, n_k, forcing_batch;
+  float inv_P, inv_nk;     // RN(1 / P), RN(1 / max(n_k, 1)): what the kernels' 1.0f / (float)P gave,
+                           // formed once on the host instead of once per wavefront
   const float4* frc;       // [batch][P] = (amplitude, omega, phase, k_index)
   const float* sp;         // [n_k][N]   spatial phase table
   const float* trig;       // [N][12] cos / sin of the spatial phases, zero padded
@@ -140,6 +143,10 @@ struct SubstepArgs {
   float* derivs_out;     // [batch][N][D] or null
   float* coeffs_out;     // [batch][N][D][G] or null
   int batch;
+#ifdef DDD_PROBES   // libddd1d_probe.so only: wave-lifetime stamps of the multi-group walk
+  unsigned long long* trace;   // [launches][kWalkTraceRows][8] s_memrealtime (100 MHz) stamps
+  int trace_row0;              // first row of this launch
+#endif
 };
 
 __device__ __forceinline__ float apply_activation(float x, int act) {

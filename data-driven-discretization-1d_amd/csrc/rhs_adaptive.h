@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
   const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
   // sample whose (sample, mode) pair this lane evaluates in forcing phase 1
   const int frc_sl = (fast_frc && tid < (kRows / p.N) * p.P)
-                         ? row_sample(tid, 1.0f / (float)p.P) : 0;
+                         ? row_sample(tid, p.inv_P) : 0;
   const bool row_live = ln.row < ln.rows_used;
 
   const double t0 = a.times[0];

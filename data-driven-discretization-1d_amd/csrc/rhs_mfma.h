@@ -279,11 +279,31 @@ __device__ __forceinline__ void tap_rows(const Lane& ln, int trow, int n,
   rows[4] = live ? base + qp2 : trow;
 }
 
+// The MFMA-packed weight arrays (w_input, w_hidden, w_final4) hold one value per
+// (row, lane); in memory, four rows to a float4 per lane -- row s of lane l at
+// ((s >> 2) * 64 + l) * 4 + (s & 3), rows zero-padded to a multiple of four --,
+// so a wavefront fetches four rows with ONE 16-byte load per lane.  A wavefront
+// keeps at most 63 loads in flight: as 120 one-dword loads the resident weights
+// were two full memory round trips at the start of every launch
+// (profiles/tools/substep_wave_trace.py), as 31 quad loads they are one.
+template <int NR>
+__device__ __forceinline__ void load_rows4(const float* __restrict__ base, int lane,
+                                           float (&w)[NR]) {
+  const float4* __restrict__ q = reinterpret_cast<const float4*>(base) + lane;
+#pragma unroll
+  for (int k = 0; k < (NR + 3) / 4; ++k) {
+    const float4 v = q[k * 64];
+    w[4 * k] = v.x;
+    if (4 * k + 1 < NR) w[4 * k + 1] = v.y;
+    if (4 * k + 2 < NR) w[4 * k + 2] = v.z;
+    if (4 * k + 3 < NR) w[4 * k + 3] = v.w;
+  }
+}
+constexpr int padded_rows4(int rows) { return (rows + 3) / 4 * 4; }
+
 __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index,
                                             int lane, float (&w)[kHidSteps]) {
-  const float* src = p.w_hidden + (size_t)hidden_index * kHidSteps * 64 + lane;
-#pragma unroll
-  for (int s = 0; s < kHidSteps; ++s) w[s] = src[s * 64];
+  load_rows4<kHidSteps>(p.w_hidden + (size_t)hidden_index * padded_rows4(kHidSteps) * 64, lane, w);
 }
 
 #define DDD_MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
@@ -492,9 +512,7 @@ __device__ __forceinline__ void fin4_mfmas(const float (&w)[fin4_regs(NG)], cons
 template <int NG>
 __device__ __forceinline__ void load_final4(const DevParams& p, int lane,
                                             float (&w)[fin4_regs(NG)]) {
-  const float* src = p.w_final4 + lane;
-#pragma unroll
-  for (int s = 0; s < fin4_regs(NG); ++s) w[s] = src[s * 64];
+  load_rows4<fin4_regs(NG)>(p.w_final4, lane, w);
 }
 
 constexpr int kFin4Ahead = 2;   // operand groups in flight ahead of the MFMAs
@@ -557,6 +575,9 @@ struct Resident {
                             // | (index of the sum in Shared::fk) << 24; 0: lane carries none
   int frc_slot;             // index of this lane's sum in Shared::fk (fixed by the lane, not by
                             // the sample), -1: the lane carries no (sample, k, sin|cos) slot
+#ifdef DDD_PROBES
+  unsigned long long* probe_stamp = nullptr;   // setup_weights: "index math done" (substep walk trace)
+#endif
 };
 
 // Forcing, phases 1 + 2, for time t:
@@ -612,12 +633,14 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR, kWide>& sm, c
   return acc;
 }
 
-template <int kRows, int kWR, bool kWide>
+// (kMasked: forcing_phase2's masked first trip -- the same bits, a third of the
+// instructions; needs Resident::frc_mask, i.e. apply_samples.)
+template <int kRows, int kWR, bool kMasked = false, bool kWide = false>
 __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
   group_barrier<kRows, kWR>();
-  return forcing_phase2<kRows, kWR>(sm, res);
+  return forcing_phase2<kRows, kWR, kMasked>(sm, res);
 }
 
 // One evaluation of finalize_time_derivative(t, predict_time_derivative(u))
@@ -761,9 +784,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs(3);
       float wf4[kFirstRows];
       if (!kKeepRows) {
-        const float* __restrict__ wsrc = (kSpec ? p.w_final4 : p.w_final4_rt) + opaque(ln.lane);
+        if constexpr (kSpec) {
+          load_rows4<kFirstRows>(p.w_final4, opaque(ln.lane), wf4);
+        } else {
+          const float* __restrict__ wsrc = p.w_final4_rt + opaque(ln.lane);
 #pragma unroll
-        for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
+          for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
+        }
       }
       int off4[kKW];
       if (kKeepRows) {
@@ -1080,6 +1107,39 @@ __device__ __forceinline__ bool forcing_is_fast(const DevParams& p) {
          spg * kTrigMax <= Shared<kRows, kWR>::kFkMax && p.P < 256;
 }
 
+// The per-lane loop invariants of the kernels that keep them resident
+// (Resident::fin4_off .. pch_idx): functions of the lane, N and G alone.
+// (Loading them from a per-model table instead -- 115 VALU instructions fewer per
+// launch -- changed nothing measurable: profiles/r3_ablation.txt.)
+template <int kRows, int kWR>
+__device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln, Resident& res) {
+  int rows[kKW];
+  tap_rows<kRows == 64>(ln, ln.row, p.N, rows);
+#pragma unroll
+  for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
+    res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
+  const int half = ln.lane >> 5;
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, rows);
+#pragma unroll
+    for (int k = 0; k < kKW; ++k)
+      res.hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
+                                  64 * half);
+    // input layer: taps 0 / 1, taps 2 / 3, tap 4, as byte addresses (one-wave
+    // groups: ds_bpermute lane addresses, rows < 64; else into Shared::un)
+    res.in_perm[t2][0] = opaque(4 * (half ? rows[1] : rows[0]));
+    res.in_perm[t2][1] = opaque(4 * (half ? rows[3] : rows[2]));
+    res.in_perm[t2][2] = opaque(4 * rows[4]);
+  }
+  const int gl = p.G >> 1;
+  const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;
+#pragma unroll
+  for (int g = 0; g < kGMax; ++g)
+    res.pch_idx[g] = opaque(pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
+                                 : wrap_row(ln.base, ln.pos, g - gl, p.N));
+}
+
 // Per-launch setup, part 1: resident registers and the tables in LDS.
 template <int kRows, int kWR, bool kHoist, bool kWide>
 __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
@@ -1087,77 +1147,70 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   constexpr int kThreads = kRows / kWR * 64;
   const int tid = group_tid<kRows, kWR>();
   constexpr int kGW = flavour_stencil(kWide);
-  for (int i = tid; i < tab_rows(kWide) * kGW; i += kThreads) {
-    const int rowi = i / kGW, g = i % kGW;
-    sm.tab[i] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
-  }
   const bool fast = forcing_is_fast<kRows, kWR>(p);
-  {
-    const int spg = kRows / p.N;
-    const int sl = row_sample(tid >> 1, 1.0f / (float)max(p.n_k, 1));   // exact
-    res.frc_slot = (fast && tid < spg * p.n_k * 2)
-                       ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
+  // ---- every load of the setup is REQUESTED before anything is consumed: the
+  // tables, then the weights in the order the evaluation needs them.  (Written
+  // as load + LDS write pairs, each pair waited for its own memory round trip
+  // before the next load went out.)
+  constexpr int kTabN = tab_rows(kWide) * kGW;
+  constexpr int kTabTrips = (kTabN + kThreads - 1) / kThreads;
+  float tabv[kTabTrips];
+#pragma unroll
+  for (int k = 0; k < kTabTrips; ++k) {
+    const int i = min(tid + k * kThreads, kTabN - 1);
+    const int rowi = i / kGW, g = i % kGW;
+    tabv[k] = rowi < 4 ? p.bias8[rowi][g] : p.ns8[rowi - 4][g];
   }
-  // staged (sample, mode) values: zero once, so that reads past a run are finite
-  for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
-    sm.pm[i] = make_float2(0.0f, 0.0f);
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
   if (!p.fixed) {
-#pragma unroll
-    for (int s = 0; s < kInSteps; ++s) res.w_in[s] = p.w_input[s * 64 + ln.lane];
+    load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
     // loop invariants the specialised one-wave integrators keep resident
     // (kHoist: the persistent kernels; a single fused substep has no loop)
     if (kHoist && kWR == 64) {
-      if (p.w_final4 != nullptr) {   // (dead in the run-time kernels, null for wide models)
-#pragma unroll
-        for (int s = 0; s < fin4_regs(4); ++s)   // buffer holds fin4_regs(4) rows (zero padded)
-          res.w_fin4[s] = p.w_final4[s * 64 + ln.lane];
-      }
-      {
-        int rows[kKW];
-        tap_rows<kRows == 64>(ln, ln.row, p.N, rows);
-#pragma unroll
-        for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
-          res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
-        const int half = ln.lane >> 5;
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          tap_rows<kRows == 64>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, rows);
-#pragma unroll
-          for (int k = 0; k < kKW; ++k)
-            res.hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
-                                        64 * half);
-          // input layer: taps 0 / 1, taps 2 / 3, tap 4, as byte addresses (one-wave
-          // groups: ds_bpermute lane addresses, rows < 64; else into Shared::un)
-          res.in_perm[t2][0] = opaque(4 * (half ? rows[1] : rows[0]));
-          res.in_perm[t2][1] = opaque(4 * (half ? rows[3] : rows[2]));
-          res.in_perm[t2][2] = opaque(4 * rows[4]);
-        }
-      }
-      const int gl = p.G >> 1;
-      const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;
-#pragma unroll
-      for (int g = 0; g < kGMax; ++g)
-        res.pch_idx[g] = opaque(pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
-                                     : wrap_row(ln.base, ln.pos, g - gl, p.N));
+      if (p.w_final4 != nullptr)   // (dead in the run-time kernels, null for wide models)
+        load_rows4<fin4_regs(4)>(p.w_final4, ln.lane, res.w_fin4);   // (zero padded to 4 groups)
     }
   }
-#pragma unroll
-  for (int i = 0; i < kTrigMax / 4; ++i) res.trig[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (fast && kHoist && kWR == 64) {
+  // cos / sin of this grid point's spatial phases (requested LAST: the register
+  // allocator copies one of these values right after the load, and that wait
+  // must not sit in front of the other requests)
+  float4 trg[kTrigMax / 4];   // (read under `fast` only)
+  if (fast) {   // wave-uniform
     const float4* __restrict__ tr =
         reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
 #pragma unroll
-    for (int i = 0; i < kTrigMax / 4; ++i) res.trig[i] = tr[i];
+    for (int i = 0; i < kTrigMax / 4; ++i) trg[i] = tr[i];
   }
+  // ---- index math (no memory) ----
+  {
+    const int spg = kRows / p.N;
+    const int sl = row_sample(tid >> 1, p.inv_nk);   // exact
+    res.frc_slot = (fast && tid < spg * p.n_k * 2)
+                       ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
+  }
+  if (!p.fixed && kHoist && kWR == 64) lane_offsets<kRows, kWR>(p, ln, res);
+  // staged (sample, mode) values: zero once, so that reads past a run are finite
+  for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
+    sm.pm[i] = make_float2(0.0f, 0.0f);
+#ifdef DDD_PROBES
+  if (res.probe_stamp != nullptr && tid == 0)
+    *res.probe_stamp = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- the tables land ----
+#pragma unroll
+  for (int k = 0; k < kTabTrips; ++k) {
+    const int i = tid + k * kThreads;
+    if (i < kTabN) sm.tab[i] = tabv[k];
+  }
+#pragma unroll
+  for (int i = 0; i < kTrigMax / 4; ++i)
+    res.trig[i] = (fast && kHoist && kWR == 64) ? trg[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (fast && p.n_k <= 4 && ln.owner) {
-    // cos/sin of this grid point's spatial phases -> the row padding
-    const float4* __restrict__ tr =
-        reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
-    *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = tr[0];
-    *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = tr[1];
+    // ... and into the row padding of the activation buffers
+    *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = trg[0];
+    *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = trg[1];
   }
   return fast;
 }
@@ -1175,9 +1228,13 @@ __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, k
 // parameters and mode runs): once per launch in the persistent integrators,
 // once per group in the multi-group substep kernel, which fetches the next
 // group's values (fetch_samples) while the current group is being evaluated.
+// fetch_samples only REQUESTS (nothing in it depends on a loaded value, so no
+// wait is placed there); apply_samples is where the values are first touched.
 struct SampleSetup {
   float a, omega, phi;   // this lane's (sample, mode) forcing parameters
-  int run;               // Resident::frc_run
+  int runs_raw;          // first mode of this lane's run | (first mode of the next run) << 8
+  int run_base;          // Resident::frc_run without the loaded part
+  int has_slot;          // 0: the lane carries no (sample, k, sin|cos) slot
 };
 
 template <int kRows, int kWR>
@@ -1185,26 +1242,28 @@ __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int blo
                                                      bool fast) {
   const int tid = group_tid<kRows, kWR>();
   const int spg = kRows / p.N;
-  SampleSetup s{0.0f, 0.0f, 0.0f, 0};
-  if (fast && tid < spg * p.P) {
-    const int fsl = row_sample(tid, 1.0f / (float)p.P);   // tid / P, exact
+  SampleSetup s{0.0f, 0.0f, 0.0f, 0, 0, 0};
+  if (fast) {   // wave-uniform
+    // Both loads are UNCONDITIONAL (lanes without a pair / slot, and samples past
+    // the batch, read entry 0: finite values that reach no stored row): a load
+    // under a lane mask is waited for where the mask closes, and a wavefront
+    // that stalls one memory round trip per load before it has even requested
+    // its weights is what made the start of a launch cost more than an
+    // evaluation (profiles/tools/substep_wave_trace.py).
+    const int fsl = row_sample(tid, p.inv_P);   // tid / P, exact
     const long sample = (long)block * spg + fsl;
-    if (sample < batch) {
-      const float4 q = p.frc[sample * p.P + (tid - fsl * p.P)];
-      s.a = q.x; s.omega = q.y; s.phi = q.z;
-    }
-  }
-  // this lane's run of modes [m0, m1): runs[sample][kk] = first (sorted) mode of
-  // the sample whose k index is >= kk, precomputed by ddd_set_forcing
-  if (fast && tid < spg * p.n_k * 2) {
-    const int sl = row_sample(tid >> 1, 1.0f / (float)p.n_k);   // exact
+    const bool has_pair = tid < spg * p.P && sample < batch;
+    const float4* __restrict__ row = p.frc + (has_pair ? sample * p.P + (tid - fsl * p.P) : 0);
+    s.a = row->x; s.omega = row->y; s.phi = row->z;
+    // this lane's run of modes [m0, m1): runs[sample][kk] = first (sorted) mode of
+    // the sample whose k index is >= kk, precomputed by ddd_set_forcing
+    const int sl = row_sample(tid >> 1, p.inv_nk);   // exact
     const int kk = (tid >> 1) - sl * p.n_k;
-    const long sample = (long)block * spg + sl;
-    if (sample < batch) {
-      const int m0 = p.runs[sample * 8 + kk], m1 = p.runs[sample * 8 + kk + 1];
-      s.run = (2 * (sl * p.P + m0) + (tid & 1)) | ((m1 - m0) << 16) |
-              ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
-    }
+    const long sample2 = (long)block * spg + sl;
+    s.has_slot = tid < spg * p.n_k * 2 && sample2 < batch;
+    const unsigned char* __restrict__ rr = p.runs + (s.has_slot ? sample2 * 8 + kk : 0);
+    s.runs_raw = (int)rr[0] | ((int)rr[1] << 8);
+    s.run_base = (2 * (sl * p.P) + (tid & 1)) | ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
   }
   return s;
 }
@@ -1216,8 +1275,10 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide>& sm, Res
                                               const SampleSetup& s) {
   constexpr int kThreads = kRows / kWR * 64;
   res.frc_a = s.a; res.frc_omega = s.omega; res.frc_phi = s.phi;
-  res.frc_run = s.run;
-  const int cnt = (s.run >> 16) & 0xff;
+  const int m0 = s.runs_raw & 0xff, m1 = s.runs_raw >> 8;
+  // (the low half stays below 2^16: 2 (samples x modes) + 1, as before)
+  res.frc_run = s.has_slot ? (s.run_base + 2 * m0) | ((m1 - m0) << 16) : 0;
+  const int cnt = (res.frc_run >> 16) & 0xff;
 #pragma unroll
   for (int i = 0; i < 8; ++i) res.frc_mask[i] = i < cnt ? 1.0f : 0.0f;
   if (kReset) {
@@ -1272,8 +1333,24 @@ __device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepAr
                                              Shared<kRows, kWR>& sm, int groups, int first,
                                              int stride) {
   const int tid = group_tid<kRows, kWR>();
+#ifdef DDD_PROBES
+  // wave lifetime: [0] first instruction, [1] weights / first sums ready, [2..5] end
+  // of each row group, [6] hardware id, [7] last instruction
+  unsigned long long* stamp =
+      a.trace != nullptr ? a.trace + ((size_t)a.trace_row0 + first) * 8 : nullptr;
+  int stamp_at = 2;
+  if (stamp != nullptr && tid == 0) {
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+    stamp[6] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+  }
+#endif
   Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, first);
   Resident res;
+#ifdef DDD_PROBES
+  res.probe_stamp = stamp != nullptr ? stamp + 4 : nullptr;   // index math of the setup done
+#endif
   // the first group's state and forcing rows are requested BEFORE the 115 weight
   // registers: its input layer and forcing sums run while the hidden layer's
   // weights are still arriving (loads return in order)
@@ -1281,27 +1358,35 @@ __device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepAr
   const bool fast_frc = forcing_is_fast<kRows, kWR>(p);
   const SampleSetup s_first = fetch_samples<kRows, kWR>(p, first, a.batch, fast_frc);
   setup_weights<kRows, kWR, true>(p, sm, ln, res);
+#ifdef DDD_PROBES
+  if (stamp != nullptr && tid == 0) stamp[5] = __builtin_amdgcn_s_memrealtime();   // loads issued
+#endif
   apply_samples<kRows, kWR>(sm, res, s_first);
-  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, tid);
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR, true>(p, sm, res, (float)a.t, tid);
+#ifdef DDD_PROBES
+  if (stamp != nullptr && tid == 0) stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int grp = first; grp < groups; grp += stride) {
     // the next group's state and forcing rows: in flight during this evaluation
     const int nxt = grp + stride;
     const bool more = nxt < groups;
     Lane ln_next = ln;
     float u_next = 0.0f;
+    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0, 0, 0};
     if (more) {
       ln_next = make_lane<kRows, kWR>(p, a.batch, tid, nxt);
       u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
-      // from here on the harmonic sums computed are the NEXT group's: this
-      // group's are already in res.fk_next and are published by eval_rhs
-      apply_samples<kRows, kWR, false>(sm, res,
-                                       fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc));
+      s_next = fetch_samples<kRows, kWR>(p, nxt, a.batch, fast_frc);
     }
     // the update's other operands: requested now, consumed after the evaluation
     const float base = (ln.active && a.y_out != nullptr && a.y_base != nullptr)
                            ? a.y_base[ln.gidx] : 0.0f;
     const float acc_in = (ln.active && a.acc_out != nullptr && a.acc_in != nullptr)
                              ? a.acc_in[ln.gidx] : 0.0f;
+    // from here on the harmonic sums computed are the NEXT group's: this
+    // group's are already in res.fk_next and are published by eval_rhs
+    // (after the requests above: one wait for all of them)
+    if (more) apply_samples<kRows, kWR, false>(sm, res, s_next);
     // `more`: the evaluation also prepares the sums of the next group (same time,
     // other samples) at its layer boundaries, as the persistent integrator does
     // for its next stage; the last group has no successor
@@ -1313,12 +1398,19 @@ __device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepAr
       if (a.y_out != nullptr) a.y_out[ln.gidx] = base + a.c1 * f;
       if (a.acc_out != nullptr) a.acc_out[ln.gidx] = acc_in + a.c2 * f;
     }
+#ifdef DDD_PROBES
+    if (stamp != nullptr && tid == 0 && stamp_at < 4)
+      stamp[stamp_at++] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (more) {
       group_barrier<kRows, kWR>();   // this group's epilogue has read sm.fk / sm.u
       ln = ln_next;
       u = u_next;
     }
   }
+#ifdef DDD_PROBES
+  if (stamp != nullptr && tid == 0) stamp[7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int kRows, int kWR, int kEq>
@@ -1354,13 +1446,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevPara
   apply_samples<kRows, kWR>(sm, res, s_first);
   const float h = (float)a.dt;
   const float t_first = (float)(a.t + a.tab.c[0] * a.dt);
-  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_first, tid);
+  if (fast_frc) res.fk_next = forcing_sums<kRows, kWR, true>(p, sm, res, t_first, tid);
   for (int grp = blockIdx.x; grp < groups; grp += stride) {
     const int nxt = grp + stride;
     const bool more = nxt < groups;
     Lane ln_next = ln;
     float u_next = 0.0f;
-    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0};
+    SampleSetup s_next{0.0f, 0.0f, 0.0f, 0, 0, 0};
     if (more) {   // in flight during this group's stages
       ln_next = make_lane<kRows, kWR>(p, a.batch, tid, nxt);
       u_next = ln_next.valid ? a.y_in[ln_next.gidx] : 0.0f;
