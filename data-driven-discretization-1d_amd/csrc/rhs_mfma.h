@@ -1,4 +1,11 @@
-// Fused learned-stencil right-hand side + Runge-Kutta stepping on CDNA4 f32 MFMA.
+// (Several independent one-wave groups per workgroup were measured slower, twice.
+// Four per 256-thread workgroup with a run-time LDS base: 35.1 vs 33.0 us per
+// substep at B = 4096.  Two per 128-thread workgroup with statically addressed LDS
+// blocks (two inlined copies of the walk): the dispatcher then puts BOTH wavefronts
+// of a launch on one SIMD for half the SIMDs, and two wavefronts in the same
+// phases of the same launch take 23 us for their first evaluation -- 64.8 % against
+// 71.6 %.  One-wave workgroups of two chains half a launch apart land exactly one
+// wavefront of each chain on every SIMD.  profiles/r3_ablation.txt.)// Fused learned-stencil right-hand side + Runge-Kutta stepping on CDNA4 f32 MFMA.
 //
 // Work decomposition (DESIGN.md "MFMA kernel"):
 //   * one workgroup = kRows "rows" (grid points) = floor(kRows / N) whole
@@ -1432,22 +1439,21 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
 // with the stage loop of the persistent integrator inside -- the state crosses
 // HBM once per step and the launch boundary is paid once per step.
 template <int kRows, int kWR, int kEq>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevParams p, StepArgs a,
-                                                                         int groups) {
-  __shared__ Shared<kRows, kWR> sm;
+__device__ __forceinline__ void step_walk(const DevParams& p, const StepArgs& a,
+                                          Shared<kRows, kWR>& sm, int groups, int first,
+                                          int stride) {
   const int tid = group_tid<kRows, kWR>();
-  const int stride = (int)gridDim.x;
-  Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, (int)blockIdx.x);
+  Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, first);
   Resident res;
   float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;
   const bool fast_frc = forcing_is_fast<kRows, kWR>(p);
-  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, blockIdx.x, a.batch, fast_frc);
+  const SampleSetup s_first = fetch_samples<kRows, kWR>(p, first, a.batch, fast_frc);
   setup_weights<kRows, kWR, true>(p, sm, ln, res);
   apply_samples<kRows, kWR>(sm, res, s_first);
   const float h = (float)a.dt;
   const float t_first = (float)(a.t + a.tab.c[0] * a.dt);
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR, true>(p, sm, res, t_first, tid);
-  for (int grp = blockIdx.x; grp < groups; grp += stride) {
+  for (int grp = first; grp < groups; grp += stride) {
     const int nxt = grp + stride;
     const bool more = nxt < groups;
     Lane ln_next = ln;
@@ -1480,6 +1486,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevPara
       u = u_next;
     }
   }
+}
+
+template <int kRows, int kWR, int kEq>
+__global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevParams p, StepArgs a,
+                                                                         int groups) {
+  __shared__ Shared<kRows, kWR> sm;
+  step_walk<kRows, kWR, kEq>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------

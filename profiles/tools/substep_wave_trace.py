@@ -77,3 +77,16 @@ print('launch %d: wave start percentiles (us after first start):' % l,
       np.percentile(s0 - s0.min(), [0, 10, 50, 90, 99, 100]).round(2).tolist())
 print('launch %d: wave end percentiles   (us after first start):' % l,
       np.percentile(end - s0.min(), [0, 10, 50, 90, 99, 100]).round(2).tolist())
+life = end - s0
+print('launch %d: wave lifetime percentiles:' % l, np.percentile(life, [0, 10, 50, 90, 99, 100]).round(2).tolist())
+keys = simd_key(T[l, u, 6])
+cnt = collections.Counter(keys.tolist())
+same = np.array([cnt[k] for k in keys.tolist()])
+for n in sorted(set(same.tolist())):
+    sel = same == n
+    print('  waves on a SIMD holding %d wave(s) of this launch: %d, lifetime median %.2f max %.2f, start median %.2f'
+          % (n, sel.sum(), np.median(life[sel]), life[sel].max(), np.median((s0 - s0.min())[sel])))
+slow = np.argsort(life)[-8:]
+print('  slowest waves: slot, start, setup, ev1, ev2:', [(int(np.nonzero(u)[0][i]), round(float(s0[i] - s0.min()), 2),
+      round(float(us(T[l, u, 1])[i] - s0[i]), 2), round(float(us(T[l, u, 2])[i] - us(T[l, u, 1])[i]), 2),
+      round(float(us(T[l, u, 3])[i] - us(T[l, u, 2])[i]), 2)) for i in slow])
