@@ -1321,19 +1321,9 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
       DDD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     DDD_HIP(hipEventRecord(m->ev_fork, stream));
     for (int i = 0; i < halves; ++i) DDD_HIP(hipStreamWaitEvent(lanes[i], m->ev_fork, 0));
-    // chain i starts i / halves of a launch late (estimate: ~6 us per launch +
-    // ~14.5 us per row group a wavefront walks over; 100 ticks of s_memrealtime = 1 us)
-    const MfmaGeometry geo = mfma_geometry(m, batch);
-    const int spg = geo.rows / m->dp.N;
-    const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
-    const int share = std::max(capacity / halves, 1);
-    const int passes = ((half_batch[0] + spg - 1) / spg + share - 1) / share;
-    const double est_us = 6.0 + 14.5 * passes * (geo.rows == 64 ? 1.0 : 4.0) *
-                                    (step_eq >= 0 ? tab.stages : 1);
-    for (int i = 1; i < halves; ++i)
-      hipLaunchKernelGGL(ddd::ops::delay_kernel, dim3(1), dim3(64), 0, lanes[i],
-                         (unsigned)(100.0 * est_us * i / halves));
-    DDD_HIP(hipGetLastError());
+    // (No start offset between the chains: whatever it is, they settle into the
+    // same steady state within a few launches -- measured 0 .. 1.75 half-launches,
+    // 72.4 +- 0.1 % throughout, profiles/r3_ablation.txt.)
   }
   size_t half_off[kMaxParts];
   for (int i = 0; i < kMaxParts; ++i) half_off[i] = (size_t)slab_first[i] * m->dp.N;

@@ -144,14 +144,6 @@ __global__ void apply_space_derivatives_kernel(const float* __restrict__ derivs,
   }
 }
 
-// Holds its stream for `ticks` of the constant 100 MHz counter (s_memrealtime):
-// staggers the second half-ensemble chain of the per-substep launch mode by
-// half a substep (capi.hip: ddd_integrate_fixed).
-__global__ void delay_kernel(unsigned ticks) {
-  const unsigned long long start = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - start < ticks) __builtin_amdgcn_s_sleep(8);
-}
-
 __global__ void dpp_rotate_probe_kernel(float* __restrict__ out) {
   out[threadIdx.x] = wave_rotate_left1((float)(threadIdx.x * 3 + 1));
 }
