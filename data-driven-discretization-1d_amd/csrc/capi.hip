@@ -170,6 +170,7 @@ struct ddd_model {
   int64_t fma_per_point = 0;
   // device allocations
   float* d_weights = nullptr;
+  float* d_weights4 = nullptr;      // channel-padded copy for the generic kernel's LDS staging
   float* d_nullspace = nullptr;
   float* d_bias = nullptr;
   float* d_w_input = nullptr;
@@ -943,6 +944,24 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   }
   rc = upload(wv, &m->d_weights);
   dp.weights = m->d_weights;
+  if (!rc) {
+    // the generic kernel stages a layer's weights in LDS with the output channels
+    // padded to fours ([K][cin][c4] + bias [c4]): kept in that form, so that the
+    // staging is a straight float4 copy (rhs_generic.h)
+    std::vector<float> w4;
+    for (int l = 0; l < dp.L; ++l) {
+      const int c4 = (dp.cout[l] + 3) & ~3;
+      dp.w4_off[l] = (int)w4.size();
+      const float* w = wv.data() + dp.w_off[l];
+      const float* b = wv.data() + dp.b_off[l];
+      for (int kc = 0; kc < dp.K * dp.cin[l]; ++kc)
+        for (int col = 0; col < c4; ++col)
+          w4.push_back(col < dp.cout[l] ? w[(size_t)kc * dp.cout[l] + col] : 0.0f);
+      for (int col = 0; col < c4; ++col) w4.push_back(col < dp.cout[l] ? b[col] : 0.0f);
+    }
+    rc = upload(w4, &m->d_weights4);
+    dp.weights4 = m->d_weights4;
+  }
   if (!rc && projected) {
     std::vector<float> nv(nullspace, nullspace + n_nullspace);
     std::vector<float> bv(bias, bias + n_bias);
@@ -1084,7 +1103,7 @@ int ddd_rk_substep_f64(ddd_model* m, double t, const double* y_in, const double*
 
 int ddd_model_destroy(ddd_model* m) {
   if (m == nullptr) return DDD_OK;
-  free_dev(m->d_weights); free_dev(m->d_nullspace); free_dev(m->d_bias);
+  free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
   free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);

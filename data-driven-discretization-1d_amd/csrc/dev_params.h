@@ -45,6 +45,8 @@ struct DevParams {
   int in_start[kMaxDerivs], in_size[kMaxDerivs], ns_off[kMaxDerivs];
   int w_off[kMaxLayers], b_off[kMaxLayers], cin[kMaxLayers], cout[kMaxLayers];
   const float* weights;    // natural layout, layer-major (kernel then bias)
+  const float* weights4;   // the same with output channels zero-padded to fours: per layer
+  int w4_off[kMaxLayers];  //   [K][cin][c4] then bias [c4] (the generic kernel's LDS image)
   const float* nullspace;  // per derivative [in_size][G]
   const float* bias;       // [D][G]  (accuracy-layer bias, or fixed stencils)
   // MFMA-path projection tables, carried in the kernel-argument segment so

@@ -85,6 +85,12 @@ __device__ __forceinline__ Carve carve(const DevParams& p, float* base, bool sta
   return c;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(float x, f32x2 w, f32x2 a) {
+  const f32x2 xx = {x, x};
+  return __builtin_elementwise_fma(xx, w, a);   // fmaf per element
+}
+
 __device__ __forceinline__ int wrap(int i, int n) {
   i %= n;
   return i < 0 ? i + n : i;
@@ -102,6 +108,7 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
     __syncthreads();
     float* cur = c.act_a;
     float* nxt = c.act_b;
+    const int cm_floats = (int)(c.act_b - c.act_a);   // both activation buffers 16-byte aligned?
     for (int l = 0; l < p.L; ++l) {
       const int cin = p.cin[l], cout = p.cout[l];
       const float* __restrict__ w = p.weights + p.w_off[l];
@@ -115,23 +122,48 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
         // activations for eight FMAs.  Same accumulation order as the plain
         // form below (tap-major, then input channel): same bits.
         const int c4 = (cout + 3) & ~3;
-        for (int i = tid; i < p.K * cin * c4; i += kThreads) {
-          const int col = i % c4, kc = i / c4;
-          c.wl[i] = col < cout ? w[(size_t)kc * cout + col] : 0.0f;
+        {   // the layer's LDS image is kept in global memory (DevParams::weights4): float4 copies
+          const float4* __restrict__ src =
+              reinterpret_cast<const float4*>(p.weights4 + p.w4_off[l]);
+          float4* __restrict__ dst = reinterpret_cast<float4*>(c.wl);
+          const int quads_total = (p.K * cin + 1) * (c4 / 4);
+          for (int i = tid; i < quads_total; i += kThreads) dst[i] = src[i];
         }
         float* bl = c.wl + (size_t)p.K * cin * c4;
-        for (int i = tid; i < c4; i += kThreads) bl[i] = i < cout ? b[i] : 0.0f;
         __syncthreads();
         const int quads = c4 / 4, pairs = (n + 1) / 2;
         for (int item = tid; item < pairs * quads; item += kThreads) {
           const int q = item % quads, pp = item / quads;
           const int pos0 = 2 * pp, pos1 = (2 * pp + 1 < n) ? 2 * pp + 1 : 2 * pp;
           float a0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, a1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          // four input channels per trip where the rows allow 16-byte reads: two
+          // ds_read_b128 of activations + four of weights for 32 FMAs, issued as
+          // packed pairs (v_pk_fma_f32: the scalar FMA rate is half the f32 peak)
+          const bool by4 = (cin & 3) == 0 && (cm_floats & 3) == 0;
           for (int k = 0; k < p.K; ++k) {
             const float* __restrict__ r0 = cur + (size_t)wrap(pos0 + k - left, n) * cin;
             const float* __restrict__ r1 = cur + (size_t)wrap(pos1 + k - left, n) * cin;
             const float4* __restrict__ wk =
                 reinterpret_cast<const float4*>(c.wl + (size_t)k * cin * c4) + q;
+            if (by4) {
+              f32x2 p0a = {a0[0], a0[1]}, p0b = {a0[2], a0[3]};
+              f32x2 p1a = {a1[0], a1[1]}, p1b = {a1[2], a1[3]};
+              for (int ci = 0; ci < cin; ci += 4) {
+                const float4 x0 = *reinterpret_cast<const float4*>(r0 + ci);
+                const float4 x1 = *reinterpret_cast<const float4*>(r1 + ci);
+                const float xs0[4] = {x0.x, x0.y, x0.z, x0.w}, xs1[4] = {x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {   // (channel order ci, ci + 1, ...: the same sums)
+                  const float4 w4 = wk[(size_t)(ci + j) * quads];
+                  const f32x2 wa = {w4.x, w4.y}, wb = {w4.z, w4.w};
+                  p0a = fma2(xs0[j], wa, p0a); p0b = fma2(xs0[j], wb, p0b);
+                  p1a = fma2(xs1[j], wa, p1a); p1b = fma2(xs1[j], wb, p1b);
+                }
+              }
+              a0[0] = p0a.x; a0[1] = p0a.y; a0[2] = p0b.x; a0[3] = p0b.y;
+              a1[0] = p1a.x; a1[1] = p1a.y; a1[2] = p1b.x; a1[3] = p1b.y;
+              continue;
+            }
             for (int ci = 0; ci < cin; ++ci) {
               const float4 w4 = wk[(size_t)ci * quads];
               const float x0 = r0[ci], x1 = r1[ci];
