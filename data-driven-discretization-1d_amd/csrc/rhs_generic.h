@@ -22,7 +22,10 @@ struct Carve {
   float* u;      // [N]
   float* flux;   // [N]
   float* dy;     // [N]
-  float* wl;     // one layer's weights [K][Cin][Cout4] + bias [Cout4], or null (does not fit)
+  float* wl;     // LDS image of the weights ([K][Cin][Cout4] + bias [Cout4] per layer): of
+                 // every layer (all_layers; staged once per launch), of one layer at a time
+                 // (staged per layer and evaluation), or null (does not fit)
+  bool all_layers;
 };
 
 // Floats of the per-layer weight stage: the largest layer with its output
@@ -36,6 +39,15 @@ __host__ __device__ inline size_t weight_stage_floats(const DevParams& p) {
   }
   return most;
 }
+// ... and of all layers together (DevParams::weights4 as it lies in memory)
+__host__ __device__ inline size_t weight_image_floats(const DevParams& p) {
+  size_t all = 0;
+  for (int l = 0; l < p.L; ++l) {
+    const size_t c4 = (size_t)((p.cout[l] + 3) & ~3);
+    all += (size_t)p.K * p.cin[l] * c4 + c4;
+  }
+  return all;
+}
 
 __host__ __device__ inline int max_channels(const DevParams& p) {
   int c = 1;
@@ -45,15 +57,16 @@ __host__ __device__ inline int max_channels(const DevParams& p) {
 
 // Bytes of dynamic LDS for `state_bytes`-wide integration state (0 for the
 // substep kernel).
-// (`staged`: with the per-layer weight stage; the stage is dropped when the
-// total would not fit the CU's 160 KiB)
+// stage: 2 = every layer's weights resident in LDS, 1 = one layer at a time,
+// 0 = none (weights read from L2): weight_stage picks.
 __host__ __device__ inline size_t lds_bytes_with(const DevParams& p, int state_bytes,
-                                                bool staged) {
+                                                int stage) {
   const size_t n = (size_t)p.N;
   size_t floats = 3 * n;
   if (!p.fixed) floats += 2 * n * (size_t)max_channels(p);
   floats = (floats + 3) & ~(size_t)3;
-  if (!p.fixed && staged) floats += weight_stage_floats(p);
+  if (!p.fixed && stage == 1) floats += weight_stage_floats(p);
+  if (!p.fixed && stage == 2) floats += weight_image_floats(p);
   size_t bytes = floats * sizeof(float);
   bytes = (bytes + 15) & ~(size_t)15;
   if (state_bytes) bytes += 2 * n * (size_t)state_bytes + n * sizeof(float);
@@ -63,16 +76,23 @@ __host__ __device__ inline size_t lds_bytes_with(const DevParams& p, int state_b
 __host__ __device__ inline size_t adaptive_extra_bytes(const DevParams& p) {
   return (size_t)p.N * (2 * sizeof(double) + 3 * sizeof(float));
 }
-__host__ __device__ inline bool weights_staged(const DevParams& p, int state_bytes,
-                                               size_t extra_bytes = 0) {
-  return !p.fixed && lds_bytes_with(p, state_bytes, true) + extra_bytes <= 160 * 1024;
+__host__ __device__ inline int weight_stage(const DevParams& p, int state_bytes,
+                                            size_t extra_bytes = 0) {
+  if (p.fixed) return 0;
+  const size_t cap = 160 * 1024;
+  const size_t b1 = lds_bytes_with(p, state_bytes, 1) + extra_bytes;
+  const size_t b2 = lds_bytes_with(p, state_bytes, 2) + extra_bytes;
+  // every layer resident only where that does not cost a workgroup per CU: the
+  // kernel is latency-bound (default net: 4 -> 3 workgroups per CU, 15.6 -> 10.2 %)
+  if (b2 <= cap && (b1 > cap || cap / b2 >= cap / b1)) return 2;
+  return b1 <= cap ? 1 : 0;
 }
 __host__ __device__ inline size_t lds_bytes(const DevParams& p, int state_bytes,
                                             size_t extra_bytes = 0) {
-  return lds_bytes_with(p, state_bytes, weights_staged(p, state_bytes, extra_bytes));
+  return lds_bytes_with(p, state_bytes, weight_stage(p, state_bytes, extra_bytes));
 }
 
-__device__ __forceinline__ Carve carve(const DevParams& p, float* base, bool staged) {
+__device__ __forceinline__ Carve carve(const DevParams& p, float* base, int stage) {
   Carve c;
   const int cm = p.fixed ? 0 : max_channels(p);
   c.act_a = base;
@@ -81,8 +101,19 @@ __device__ __forceinline__ Carve carve(const DevParams& p, float* base, bool sta
   c.flux = c.u + p.N;
   c.dy = c.flux + p.N;
   const size_t front = ((size_t)(3 * p.N) + 2 * (size_t)p.N * cm + 3) & ~(size_t)3;
-  c.wl = (!p.fixed && staged) ? base + front : nullptr;
+  c.wl = (!p.fixed && stage > 0) ? base + front : nullptr;
+  c.all_layers = stage == 2;
   return c;
+}
+
+// stage 2: the whole weight image, once per launch (all threads; ends with a barrier)
+__device__ __forceinline__ void stage_all_layers(const DevParams& p, const Carve& c) {
+  if (c.wl == nullptr || !c.all_layers) return;
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(p.weights4);
+  float4* __restrict__ dst = reinterpret_cast<float4*>(c.wl);
+  const int quads_total = (int)(weight_image_floats(p) / 4);
+  for (int i = threadIdx.x; i < quads_total; i += kThreads) dst[i] = src[i];
+  __syncthreads();
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -122,15 +153,17 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
         // activations for eight FMAs.  Same accumulation order as the plain
         // form below (tap-major, then input channel): same bits.
         const int c4 = (cout + 3) & ~3;
-        {   // the layer's LDS image is kept in global memory (DevParams::weights4): float4 copies
+        const float* __restrict__ wl = c.wl + (c.all_layers ? p.w4_off[l] : 0);
+        if (!c.all_layers) {
+          // the layer's LDS image is kept in global memory (DevParams::weights4): float4 copies
           const float4* __restrict__ src =
               reinterpret_cast<const float4*>(p.weights4 + p.w4_off[l]);
           float4* __restrict__ dst = reinterpret_cast<float4*>(c.wl);
           const int quads_total = (p.K * cin + 1) * (c4 / 4);
           for (int i = tid; i < quads_total; i += kThreads) dst[i] = src[i];
+          __syncthreads();
         }
-        float* bl = c.wl + (size_t)p.K * cin * c4;
-        __syncthreads();
+        const float* bl = wl + (size_t)p.K * cin * c4;
         const int quads = c4 / 4, pairs = (n + 1) / 2;
         for (int item = tid; item < pairs * quads; item += kThreads) {
           const int q = item % quads, pp = item / quads;
@@ -144,7 +177,7 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
             const float* __restrict__ r0 = cur + (size_t)wrap(pos0 + k - left, n) * cin;
             const float* __restrict__ r1 = cur + (size_t)wrap(pos1 + k - left, n) * cin;
             const float4* __restrict__ wk =
-                reinterpret_cast<const float4*>(c.wl + (size_t)k * cin * c4) + q;
+                reinterpret_cast<const float4*>(wl + (size_t)k * cin * c4) + q;
             if (by4) {
               f32x2 p0a = {a0[0], a0[1]}, p0b = {a0[2], a0[3]};
               f32x2 p1a = {a1[0], a1[1]}, p1b = {a1[2], a1[3]};
@@ -281,7 +314,8 @@ __device__ inline void eval_rhs(const DevParams& p, const Carve& c, long sample,
 
 __global__ __launch_bounds__(kThreads) void substep_kernel(DevParams p, SubstepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const Carve c = carve(p, smem, weights_staged(p, 0));
+  const Carve c = carve(p, smem, weight_stage(p, 0));
+  stage_all_layers(p, c);
   const long sample = blockIdx.x;
   const size_t off = (size_t)sample * p.N;
   for (int i = threadIdx.x; i < p.N; i += kThreads) c.u[i] = a.y_in[off + i];
@@ -303,8 +337,9 @@ __global__ __launch_bounds__(kThreads) void substep_kernel(DevParams p, SubstepA
 template <typename ST>
 __global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, IntegrateArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const bool staged = weights_staged(p, (int)sizeof(ST));
+  const int staged = weight_stage(p, (int)sizeof(ST));
   const Carve c = carve(p, smem, staged);
+  stage_all_layers(p, c);
   const size_t front = (lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15;
   ST* y = reinterpret_cast<ST*>(reinterpret_cast<char*>(smem) + front);
   ST* ynew = y + p.N;
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(kThreads) void integrate_kernel(DevParams p, Integr
 // Dynamic LDS of adaptive_kernel: the front part + y, y_new (float64) and three
 // stage derivatives (float32) per grid point.
 __host__ __device__ inline size_t adaptive_lds_bytes(const DevParams& p) {
-  const bool staged = weights_staged(p, 0, adaptive_extra_bytes(p) + 16);
+  const int staged = weight_stage(p, 0, adaptive_extra_bytes(p) + 16);
   return ((lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15) + adaptive_extra_bytes(p);
 }
 
@@ -364,8 +399,9 @@ __host__ __device__ inline size_t adaptive_lds_bytes(const DevParams& p) {
 __global__ __launch_bounds__(kThreads) void adaptive_kernel(DevParams p, AdaptiveArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ double red[4];
-  const bool staged = weights_staged(p, 0, adaptive_extra_bytes(p) + 16);
+  const int staged = weight_stage(p, 0, adaptive_extra_bytes(p) + 16);
   const Carve c = carve(p, smem, staged);
+  stage_all_layers(p, c);
   const size_t front = (lds_bytes_with(p, 0, staged) + 15) & ~(size_t)15;
   double* y = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + front);
   double* y_new = y + p.N;
