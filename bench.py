@@ -570,7 +570,7 @@ def _differentiator_config(args):
   flops = 2.0 * diff.model.fma_per_point * n
   result = {
       'workload': 'Differentiator.__call__(t, y[{}]) -> dy/dt, batch 1, host arrays in and '
-                  'out (H2D + one fused launch + D2H per call), {} calls'.format(n, calls),
+                  'out (page-locked rows read / written by the kernel itself: one fused launch + one stream sync per call), {} calls'.format(n, calls),
       'value': us, 'unit': 'us/evaluation', 'higher_is_better': False,
       'evaluations_per_s': 1e6 / us, 'kernel': diff.model.kernel_name,
       'bound': 'latency', 'fp32_tflops': flops / (us * 1e-6) / 1e12,

@@ -84,6 +84,7 @@ class _HipDifferentiator(Differentiator):
   def __init__(self, device_model):
     self.model = device_model
     self._torch = _lib.require_gpu()
+    self._pinned = None   # (input, output) page-locked host rows the kernel reads / writes
 
   @property
   def device_model(self):
@@ -91,9 +92,24 @@ class _HipDifferentiator(Differentiator):
     return self.model
 
   def __call__(self, t: float, y: np.ndarray) -> np.ndarray:
-    y32 = np.ascontiguousarray(np.asarray(y, dtype=np.float32)[np.newaxis, :])
-    out = self.model.time_derivative(y32, t)
-    return out[0].cpu().numpy()
+    # One sample per call is all latency: the state goes into a page-locked host
+    # row the kernel reads directly (and writes its result next to), so a call is
+    # one launch and one stream synchronisation -- no staging copies, no
+    # allocations (256 B each way over the host link).
+    torch = self._torch
+    if self._pinned is None:
+      n = self.model.num_points
+      rows = torch.empty((2, 1, n), dtype=torch.float32).pin_memory()
+      self._pinned = (rows[0], rows[1], rows[0].numpy(), rows[1].numpy())
+    y_in, dydt, y_np, dydt_np = self._pinned
+    y = np.asarray(y)
+    if y.shape != (y_np.shape[1],):
+      raise ValueError('solution has unexpected size for equation: {} vs {}'
+                       .format(y.shape, y_np.shape[1]))
+    y_np[0, :] = y   # cast to float32, as the reference feeds its float32 placeholder
+    self.model.time_derivative_rows(y_in, dydt, t)
+    torch.cuda.current_stream().synchronize()
+    return dydt_np[0].copy()
 
 
 class SavedModelDifferentiator(_HipDifferentiator):

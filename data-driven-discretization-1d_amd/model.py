@@ -246,6 +246,15 @@ class _DeviceModel(object):
                                        _lib.current_stream()))
     return out
 
+  def time_derivative_rows(self, y, out, t: float = 0.0):
+    """time_derivative on caller-owned float32 rows [batch, x] the device can
+    address (device tensors or page-locked host tensors); enqueued on the
+    current stream, nothing is copied, allocated or synchronised."""
+    lib = _lib.load_library()
+    _lib.check(lib.ddd_time_derivative(self._handle, float(t), y.data_ptr(),
+                                       out.data_ptr(), y.shape[0],
+                                       _lib.current_stream()))
+
   def space_derivatives(self, y):
     """[batch, x] -> [batch, x, derivative]."""
     lib = _lib.load_library()
