@@ -661,8 +661,12 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     const long pts = (long)ddd::stream::samples_per_block(m->dp.N) * m->dp.N;
     const long total = (long)a.batch * m->dp.N;
     const unsigned blocks = (unsigned)((total + pts - 1) / pts);
-    hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel, dim3(blocks),
-                       dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
+    if (ddd::stream::quads_for(m->dp.N) == 2)
+      hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel<2>, dim3(blocks),
+                         dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
+    else
+      hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel<1>, dim3(blocks),
+                         dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
     m->last_launch_streamed = true;
     DDD_HIP(hipGetLastError());
     return DDD_OK;

@@ -4,9 +4,10 @@
 //   integrate.PolynomialDifferentiator integrate.py:74-105
 // With one launch per substep this is the only HBM-shaped kernel of the path
 // (~20 FMA against 8-12 B per grid point), so it is written as a stream: each
-// thread owns four consecutive grid points (one float4 per array), a block
-// stages 1024 points (whole samples) in LDS for the periodic stencil reads,
-// and the grid is batch * N / 1024 blocks -- no per-sample workgroup setup.
+// thread owns eight consecutive grid points (two float4 per array; four where
+// N is not a multiple of eight), a block stages 2048 (1024) points -- whole
+// samples -- in LDS for the periodic stencil reads, and the grid is
+// batch * N / 2048 blocks -- no per-sample workgroup setup.
 // Unforced equations only (KdV, KS, unforced Burgers); forced or odd-sized
 // cases keep the per-sample kernels (rhs_mfma.h / rhs_generic.h).
 #pragma once
@@ -16,22 +17,25 @@ namespace ddd {
 namespace stream {
 
 constexpr int kThreads = 256;
-constexpr int kPer = 4;                       // consecutive grid points per thread
-constexpr int kTilePoints = kThreads * kPer;  // grid points per block
-constexpr int kWin = kPer + 1 + kGMax - 1;    // stencil window of one thread (flux form: +1)
-
-__host__ __device__ inline int samples_per_block(int n) { return kTilePoints / n; }
+// kQuads: float4 rows per thread and array (2 where N % 8 == 0, else 1)
+constexpr int kMaxTilePoints = kThreads * 8;
+__host__ __device__ inline int quads_for(int n) { return n % 8 == 0 && n <= kThreads * 8 ? 2 : 1; }
+__host__ __device__ inline int samples_per_block(int n) { return kThreads * 4 * quads_for(n) / n; }
 
 // The configurations this kernel covers (checked on the host before launch).
 inline bool supports(const DevParams& p) {
-  return p.fixed && !p.weno && !p.forced && p.N >= 8 && p.N <= kTilePoints && p.N % kPer == 0 &&
-         p.G <= kGMax;
+  return p.fixed && !p.weno && !p.forced && p.N >= 8 && p.N <= kThreads * 4 * quads_for(p.N) &&
+         p.N % 4 == 0 && p.G <= kGMax;
 }
 
+template <int kQuads>
 __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, SubstepArgs a) {
+  constexpr int kPer = 4 * kQuads;              // consecutive grid points per thread
+  constexpr int kTilePoints = kThreads * kPer;  // grid points per block
+  constexpr int kWin = kPer + 1 + kGMax - 1;    // stencil window of one thread (flux form: +1)
   __shared__ float tile[kTilePoints];
   const int n = p.N;
-  const int pts = samples_per_block(n) * n;                 // multiple of 4, <= 1024
+  const int pts = samples_per_block(n) * n;                 // multiple of kPer, <= kTilePoints
   const long base = (long)blockIdx.x * pts;
   const long total = (long)a.batch * n;
   const long rest = total - base;
@@ -41,20 +45,31 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
   // operands are not needed before the stencil is done: their latency hides
   // behind the LDS exchange and the arithmetic)
   const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 base_in = zero4, acc_in4 = zero4;
+  float4 base_in[kQuads], acc_in4[kQuads];
+#pragma unroll
+  for (int k = 0; k < kQuads; ++k) { base_in[k] = zero4; acc_in4[k] = zero4; }
   if (i0 < live) {
     const long gi0 = base + i0;
-    *reinterpret_cast<float4*>(tile + i0) = *reinterpret_cast<const float4*>(a.y_in + gi0);
-    if (a.y_out != nullptr && a.y_base != nullptr && a.y_base != a.y_in)
-      base_in = *reinterpret_cast<const float4*>(a.y_base + gi0);
-    if (a.acc_out != nullptr && a.acc_in != nullptr && a.acc_in != a.y_in)
-      acc_in4 = *reinterpret_cast<const float4*>(a.acc_in + gi0);
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k)
+      *reinterpret_cast<float4*>(tile + i0 + 4 * k) =
+          *reinterpret_cast<const float4*>(a.y_in + gi0 + 4 * k);
+    if (a.y_out != nullptr && a.y_base != nullptr && a.y_base != a.y_in) {
+#pragma unroll
+      for (int k = 0; k < kQuads; ++k)
+        base_in[k] = *reinterpret_cast<const float4*>(a.y_base + gi0 + 4 * k);
+    }
+    if (a.acc_out != nullptr && a.acc_in != nullptr && a.acc_in != a.y_in) {
+#pragma unroll
+      for (int k = 0; k < kQuads; ++k)
+        acc_in4[k] = *reinterpret_cast<const float4*>(a.acc_in + gi0 + 4 * k);
+    }
   }
   __syncthreads();
   if (i0 >= live) return;
 
   const int s0 = (i0 / n) * n;     // first point of this thread's sample inside the tile
-  const int pos0 = i0 - s0;        // its four points are pos0 .. pos0 + 3 (N % 4 == 0)
+  const int pos0 = i0 - s0;        // its points are pos0 .. pos0 + kPer - 1 (N % kPer == 0)
   const int gl = p.G >> 1;         // patches[i] = u[(x + i - G/2) mod N]  (model.py:516-533)
   float w[kWin];
 #pragma unroll
@@ -65,9 +80,16 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
     w[j] = tile[s0 + q];
   }
   // the points themselves (window entry gl + q, read directly: gl is a run-time value)
-  const float4 own = *reinterpret_cast<const float4*>(tile + i0);
+  float4 own[kQuads];
+#pragma unroll
+  for (int k = 0; k < kQuads; ++k) own[k] = *reinterpret_cast<const float4*>(tile + i0 + 4 * k);
   const int qn = pos0 + kPer >= n ? pos0 + kPer - n : pos0 + kPer;
-  const float uc[kPer + 1] = {own.x, own.y, own.z, own.w, tile[s0 + qn]};
+  float uc[kPer + 1];
+#pragma unroll
+  for (int k = 0; k < kQuads; ++k) {
+    uc[4 * k] = own[k].x; uc[4 * k + 1] = own[k].y; uc[4 * k + 2] = own[k].z; uc[4 * k + 3] = own[k].w;
+  }
+  uc[kPer] = tile[s0 + qn];
   // u_t (plain forms) or the flux (flux forms; one extra point for the
   // staggered difference, equations.staggered_first_derivative)
   float f[kPer + 1];
@@ -95,21 +117,29 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
 
   const long gi = base + i0;
   if (a.y_out != nullptr) {
-    float4 o = make_float4(a.c1 * r[0], a.c1 * r[1], a.c1 * r[2], a.c1 * r[3]);
-    if (a.y_base != nullptr) {
-      // stage 0 reads y as both input and base: reuse the staged tile
-      const float4 b = a.y_base == a.y_in ? own : base_in;
-      o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k) {
+      float4 o = make_float4(a.c1 * r[4 * k], a.c1 * r[4 * k + 1], a.c1 * r[4 * k + 2],
+                             a.c1 * r[4 * k + 3]);
+      if (a.y_base != nullptr) {
+        // stage 0 reads y as both input and base: reuse the staged tile
+        const float4 b = a.y_base == a.y_in ? own[k] : base_in[k];
+        o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+      }
+      *reinterpret_cast<float4*>(a.y_out + gi + 4 * k) = o;
     }
-    *reinterpret_cast<float4*>(a.y_out + gi) = o;
   }
   if (a.acc_out != nullptr) {
-    float4 o = make_float4(a.c2 * r[0], a.c2 * r[1], a.c2 * r[2], a.c2 * r[3]);
-    if (a.acc_in != nullptr) {
-      const float4 b = a.acc_in == a.y_in ? own : acc_in4;
-      o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k) {
+      float4 o = make_float4(a.c2 * r[4 * k], a.c2 * r[4 * k + 1], a.c2 * r[4 * k + 2],
+                             a.c2 * r[4 * k + 3]);
+      if (a.acc_in != nullptr) {
+        const float4 b = a.acc_in == a.y_in ? own[k] : acc_in4[k];
+        o = make_float4(b.x + o.x, b.y + o.y, b.z + o.z, b.w + o.w);
+      }
+      *reinterpret_cast<float4*>(a.acc_out + gi + 4 * k) = o;
     }
-    *reinterpret_cast<float4*>(a.acc_out + gi) = o;
   }
 }
 
