@@ -67,13 +67,15 @@ struct DevParams {
   // kernels.  The specialised kernels know at compile time whether w_final4 is
   // folded: rhs_mfma.h spec_folded).
   int folded;
-  const float* w_input;    // MFMA-packed input layer, 3 x 64
-  const float* w_hidden;   // MFMA-packed hidden layers, (L-2) x 81 x 64
-  // output layer packed for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4), 41 x 64:
+  // MFMA-packed weights: rows x 64 lanes, stored four rows to a float4 per lane with the
+  // rows zero-padded to a multiple of four (rhs_mfma.h load_rows4)
+  const float* w_input;    // input layer, 3 rows
+  const float* w_hidden;   // hidden layers, (L-2) x 81 rows (each layer padded to 84)
+  // output layer packed for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4), 41 rows:
   const float* w_final4;      // live channels renumbered contiguously, ceil(channels / 4) groups
   // run-time-parameterised kernels: the live channel groups packed two by two
   // (pair gp: fin4_regs(2) rows for groups 2 gp, 2 gp + 1; an odd last group:
-  // fin4_regs(1) rows), channels in natural / G d + g (folded) numbering
+  // fin4_regs(1) rows), channels in natural / G d + g (folded) numbering; plain [rows][64]
   const float* w_final4_rt;
   int rt_groups;              // live channel groups of w_final4_rt
   int fin4_groups;            // groups of w_final4
