@@ -1,11 +1,4 @@
-// (Several independent one-wave groups per workgroup were measured slower, twice.
-// Four per 256-thread workgroup with a run-time LDS base: 35.1 vs 33.0 us per
-// substep at B = 4096.  Two per 128-thread workgroup with statically addressed LDS
-// blocks (two inlined copies of the walk): the dispatcher then puts BOTH wavefronts
-// of a launch on one SIMD for half the SIMDs, and two wavefronts in the same
-// phases of the same launch take 23 us for their first evaluation -- 64.8 % against
-// 71.6 %.  One-wave workgroups of two chains half a launch apart land exactly one
-// wavefront of each chain on every SIMD.  profiles/r3_ablation.txt.)// Fused learned-stencil right-hand side + Runge-Kutta stepping on CDNA4 f32 MFMA.
+// Fused learned-stencil right-hand side + Runge-Kutta stepping on CDNA4 f32 MFMA.
 //
 // Work decomposition (DESIGN.md "MFMA kernel"):
 //   * one workgroup = kRows "rows" (grid points) = floor(kRows / N) whole
@@ -1428,11 +1421,14 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
   substep_walk<kRows, kWR, kEq>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
 }
 
-// (Four independent one-wave groups per 256-thread workgroup -- which would put
-// exactly one wavefront of a launch on every SIMD, where one-wave workgroups
-// land two on one SIMD and none on another for ~10 % of the SIMDs -- was
-// measured slower: 35.1 vs 33.0 us per substep at B = 4096, the per-wavefront LDS
-// base costs registers the walk does not have.  profiles/r3_ablation.txt.)
+// (Several independent one-wave groups per workgroup were measured slower, twice.
+// Four per 256-thread workgroup with a run-time LDS base: 35.1 vs 33.0 us per
+// substep at B = 4096.  Two per 128-thread workgroup with statically addressed LDS
+// blocks (two inlined copies of the walk): the dispatcher then puts BOTH wavefronts
+// of a launch on one SIMD for half the SIMDs, and two wavefronts in the same
+// phases of the same launch take 23 us for their first evaluation -- 64.8 % against
+// 71.6 %.  One-wave workgroups of two chains (whatever their start offset) land exactly one
+// wavefront of each chain on every SIMD.  profiles/r3_ablation.txt.)
 
 // Kernel 1c: ALL stages of one Runge-Kutta step in one launch, for callers that
 // do not need the substeps (DDD_LAUNCH_PER_STEP): the same walk over row groups
