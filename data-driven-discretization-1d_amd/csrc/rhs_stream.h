@@ -18,14 +18,13 @@ namespace stream {
 
 constexpr int kThreads = 256;
 // kQuads: float4 rows per thread and array (2 where N % 8 == 0, else 1)
-constexpr int kMaxTilePoints = kThreads * 8;
-__host__ __device__ inline int quads_for(int n) { return n % 8 == 0 && n <= kThreads * 8 ? 2 : 1; }
+__host__ __device__ inline int quads_for(int n) { return n % 8 == 0 ? 2 : 1; }
 __host__ __device__ inline int samples_per_block(int n) { return kThreads * 4 * quads_for(n) / n; }
 
 // The configurations this kernel covers (checked on the host before launch).
 inline bool supports(const DevParams& p) {
-  return p.fixed && !p.weno && !p.forced && p.N >= 8 && p.N <= kThreads * 4 * quads_for(p.N) &&
-         p.N % 4 == 0 && p.G <= kGMax;
+  return p.fixed && !p.weno && !p.forced && p.N >= 8 && p.N <= kThreads * 4 && p.N % 4 == 0 &&
+         p.G <= kGMax;
 }
 
 template <int kQuads>
