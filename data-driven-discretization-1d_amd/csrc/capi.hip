@@ -1766,7 +1766,7 @@ int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0;
 // logged).  Names: no_fold (takes effect at ddd_model_create), no_spec,
 // no_stream, prio_split, stagger, substep_parts, ablate, trace_ptr, walk_trace_ptr; "reset" puts
 // every switch back to its default (the switches are process-global).
-int ddd_debug_set_option(const char* name, long long value) {
+DDD_API int ddd_debug_set_option(const char* name, long long value) {
   if (name == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "name is NULL");
   const std::string key(name);
   if (key == "no_fold") g_debug.no_fold = (int)value;
@@ -1785,7 +1785,7 @@ int ddd_debug_set_option(const char* name, long long value) {
   return DDD_OK;
 }
 
-int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
+DDD_API int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
   unsigned* d = nullptr;
   DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d), (size_t)blocks * 4 * sizeof(unsigned)));
   hipLaunchKernelGGL(ddd::ops::hwid_probe_kernel, dim3(blocks), dim3(64), 0, nullptr, d, spin);
@@ -1798,7 +1798,7 @@ int ddd_debug_hwid(unsigned* out_host, int blocks, int spin) {
 // Issue-port sharing probe (ops.h: issue_share_probe_kernel).  Returns mean
 // s_memtime ticks per operation for the MFMA streamers (slot 0) and the
 // workers (slot 1) over `blocks` workgroups.
-int ddd_debug_issue_share(int mfma_kind, int work_kind, int blocks, int iters, int prio,
+DDD_API int ddd_debug_issue_share(int mfma_kind, int work_kind, int blocks, int iters, int prio,
                           double* mfma_ticks_per_op, double* work_ticks_per_op) {
   unsigned long long* d = nullptr;
   const size_t words = (size_t)blocks * 8 * 4;
@@ -1835,7 +1835,7 @@ int ddd_debug_issue_share(int mfma_kind, int work_kind, int blocks, int iters, i
   return DDD_OK;
 }
 
-int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* ticks_per_mfma,
+DDD_API int ddd_debug_mfma_rate(int chains, int is32, int blocks, int iters, double* ticks_per_mfma,
                         double* wall_ns_per_mfma) {
   unsigned long long* d = nullptr;
   DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d), (size_t)blocks * 2 * sizeof(unsigned long long)));

@@ -38,6 +38,14 @@ extern "C" {
 #endif
 
 #define DDD_ABI_VERSION 1
+/* libddd1d.so is built with -fvisibility=hidden: the entry points below are its
+ * whole dynamic symbol table (tests/test_cpu_host_api.py compares `nm -D`
+ * with this header). */
+#if defined(__GNUC__)
+#define DDD_API __attribute__((visibility("default")))
+#else
+#define DDD_API
+#endif
 #define DDD_MAX_DERIVATIVES 4 /* Godunov KS uses 4 (equations.py:570-574) */
 #define DDD_MAX_STENCIL 16
 #define DDD_MAX_LAYERS 8
@@ -161,7 +169,7 @@ typedef struct ddd_model ddd_model;
  *             NULL unless target = coefficients with accuracy order > 0.
  *   bias      [D][G] float32 of PolynomialAccuracyLayer.bias; same condition.
  */
-int ddd_model_create(const ddd_config* cfg, const float* weights,
+DDD_API int ddd_model_create(const ddd_config* cfg, const float* weights,
                      size_t n_weights, const float* nullspace,
                      size_t n_nullspace, const float* bias, size_t n_bias,
                      ddd_model** out);
@@ -173,7 +181,7 @@ int ddd_model_create(const ddd_config* cfg, const float* weights,
  * multiplies u[x + i - G/2] (the alignment of layers.pad_periodic(center=True),
  * layers.py:76-79).  Net fields of cfg are ignored.  Also used for
  * num_layers = 0 models (model.py:496-502) after folding on the host. */
-int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
+DDD_API int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
                         size_t n_stencils, ddd_model** out);
 
 /* Replaces: integrate.SpectralDifferentiator.__init__ (integrate.py:110-111)
@@ -188,10 +196,10 @@ int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
  * integrate.py:346-347), N <= 2048.  Only the *_f64 entry points below accept
  * such a model; it carries no forcing (finalize_time_derivative stays on the
  * host, where the reference evaluates it in float64). */
-int ddd_spectral_create(const ddd_config* cfg, const double* kernels,
+DDD_API int ddd_spectral_create(const ddd_config* cfg, const double* kernels,
                         size_t n_kernels, ddd_model** out);
 
-int ddd_model_destroy(ddd_model* model);
+DDD_API int ddd_model_destroy(ddd_model* model);
 
 /* ---- per-sample forcing -------------------------------------------------
  * Replaces: RandomForcing.__call__ inside finalize_time_derivative
@@ -206,18 +214,18 @@ int ddd_model_destroy(ddd_model* model);
  * forcing_b(x_i, t) = sum_j amplitude * sin((omega*t + spatial_phase) + phase),
  * accumulated in float32 in that order (the TF graph's order).  Ignored by
  * equations whose finalize_time_derivative is the identity (KdV, KS). */
-int ddd_set_forcing(ddd_model* model, int batch, int nparams,
+DDD_API int ddd_set_forcing(ddd_model* model, int batch, int nparams,
                     const float* amplitude, const float* omega,
                     const float* phase, const int32_t* k_index,
                     const float* spatial_phase, int n_k);
-int ddd_clear_forcing(ddd_model* model);
+DDD_API int ddd_clear_forcing(ddd_model* model);
 
 /* ---- the hot path --------------------------------------------------------*/
 
 /* Replaces: Differentiator.__call__(t, y) (integrate.py:70-71, 94-95), batched:
  * dydt[b] = finalize_time_derivative(t, predict_time_derivative(y[b])).
  * y, dydt: [batch][N] float32. */
-int ddd_time_derivative(ddd_model* model, double t, const float* y,
+DDD_API int ddd_time_derivative(ddd_model* model, double t, const float* y,
                         float* dydt, int batch, void* stream);
 
 /* ONE fused launch = one Runge-Kutta substep:
@@ -226,7 +234,7 @@ int ddd_time_derivative(ddd_model* model, double t, const float* y,
  *     acc_out = acc_in + c2 * f          (skipped when acc_out NULL;
  *                                         acc_in NULL -> c2 * f)
  * All arrays [batch][N] float32; y_out / acc_out may alias their inputs. */
-int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
+DDD_API int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
                    const float* y_base, float c1, float* y_out,
                    const float* acc_in, float c2, float* acc_out, int batch,
                    void* stream);
@@ -237,14 +245,14 @@ int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
  * Advances n_steps steps of size dt from (t0, y0); every `save_every` steps
  * the state is written to y_out[(step+1)/save_every - 1][batch][N]
  * (n_steps / save_every snapshots).  y0 is not modified. */
-int ddd_integrate_fixed(ddd_model* model, int scheme, int launch_mode,
+DDD_API int ddd_integrate_fixed(ddd_model* model, int scheme, int launch_mode,
                         double t0, double dt, int n_steps, int save_every,
                         const float* y0, float* y_out, int batch, void* stream);
 
 /* Same, integration state and I/O in float64 (right-hand side stays float32,
  * as in the reference where SciPy holds y in float64 and TF evaluates in
  * float32: integrate.py:57-60, 154).  Persistent launch mode only. */
-int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
+DDD_API int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
                             int n_steps, int save_every, const double* y0,
                             double* y_out, int batch, void* stream);
 
@@ -276,7 +284,7 @@ int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, double dt,
  * sample; spectral models (ddd_spectral_create: SpectralDifferentiator, the
  * "exact" KdV / KS solver, integrate.py:108-121) with a float64 right-hand
  * side. */
-int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
+DDD_API int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
                                int n_times, double rtol, double atol,
                                double max_step, long long max_attempts,
                                const double* y0, double* y_out, int32_t* nfev,
@@ -289,9 +297,9 @@ int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
  *   f = equation_of_motion(y_in);  y_out = y_base + c1 f;  acc_out = acc_in + c2 f
  * ddd_integrate_fixed_f64 on a spectral model steps with one fused launch per
  * substep, state and right-hand side in float64. */
-int ddd_time_derivative_f64(ddd_model* model, double t, const double* y,
+DDD_API int ddd_time_derivative_f64(ddd_model* model, double t, const double* y,
                             double* dydt, int batch, void* stream);
-int ddd_rk_substep_f64(ddd_model* model, double t, const double* y_in,
+DDD_API int ddd_rk_substep_f64(ddd_model* model, double t, const double* y_in,
                        const double* y_base, double c1, double* y_out,
                        const double* acc_in, double c2, double* acc_out,
                        int batch, void* stream);
@@ -304,19 +312,19 @@ int ddd_rk_substep_f64(ddd_model* model, double t, const double* y_in,
  * `kernel` [n] (device) is the operator applied to a unit impulse at x = 0
  * (smoothing_filter(delta, alpha, order)); in / out [rows][n]; out may alias in.
  * n <= 2048. */
-int ddd_circulant_apply_f64(const double* kernel, const double* in, double* out,
+DDD_API int ddd_circulant_apply_f64(const double* kernel, const double* in, double* out,
                             int rows, int n, void* stream);
 
 /* ---- parity / debugging views of the same kernel ------------------------ */
 
 /* Replaces: model.predict_space_derivatives (model.py:579-600) or
  * baseline_space_derivatives; out [batch][N][D]. */
-int ddd_space_derivatives(ddd_model* model, const float* y, float* out,
+DDD_API int ddd_space_derivatives(ddd_model* model, const float* y, float* out,
                           int batch, void* stream);
 
 /* Replaces: model.predict_coefficients (model.py:420-513);
  * out [batch][N][D][G]. */
-int ddd_coefficients(ddd_model* model, const float* y, float* out, int batch,
+DDD_API int ddd_coefficients(ddd_model* model, const float* y, float* out, int batch,
                      void* stream);
 
 /* ---- standalone operators (reference unit-test surface) ------------------ */
@@ -324,57 +332,57 @@ int ddd_coefficients(ddd_model* model, const float* y, float* out, int batch,
 /* Replaces: layers.nn_conv1d_periodic / conv1d_periodic_layer
  * (layers.py:95-137).  in [batch][N][Cin], filters [K][Cin][Cout] (device),
  * bias [Cout] or NULL, out [batch][N][Cout]; activation -1 = none. */
-int ddd_conv1d_periodic(const float* in, const float* filters,
+DDD_API int ddd_conv1d_periodic(const float* in, const float* filters,
                         const float* bias, float* out, int batch, int n,
                         int cin, int cout, int k, int center, int activation,
                         void* stream);
 
 /* Replaces: layers.pad_periodic (layers.py:39-83).
  * in [batch][N][C] -> out [batch][N + padding][C]. */
-int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c,
+DDD_API int ddd_pad_periodic(const float* in, float* out, int batch, int n, int c,
                      int padding, int center, void* stream);
 
 /* Replaces: model.extract_patches (model.py:516-533).
  * in [batch][N] -> out [batch][N][size], out[b][x][i] = in[b][(x + i - size/2) mod N]. */
-int ddd_extract_patches(const float* in, float* out, int batch, int n, int size,
+DDD_API int ddd_extract_patches(const float* in, float* out, int batch, int n, int size,
                         void* stream);
 
 /* Replaces: model.apply_coefficients (model.py:536-548).
  * coefficients [batch][N][D][G], in [batch][N] -> out [batch][N][D]. */
-int ddd_apply_coefficients(const float* coefficients, const float* in, float* out,
+DDD_API int ddd_apply_coefficients(const float* coefficients, const float* in, float* out,
                            int batch, int n, int d, int g, void* stream);
 
 /* Replaces: model.apply_space_derivatives (model.py:115-135):
  * Equation.equation_of_motion on given derivatives [batch][N][D] (order of
  * DERIVATIVE_NAMES) and the state y [batch][N] -> time derivative [batch][N],
  * without finalize_time_derivative.  `equation` is a ddd_equation. */
-int ddd_apply_space_derivatives(int equation, const float* derivatives, const float* y,
+DDD_API int ddd_apply_space_derivatives(int equation, const float* derivatives, const float* y,
                                 float* out, int batch, int n, int d, double eta,
                                 double dx, void* stream);
 
 /* Replaces: PolynomialAccuracyLayer.apply (polynomials.py:266-277).
  * inputs [m][input_size], nullspace [input_size][G], bias [G], out [m][G]. */
-int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
+DDD_API int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
                                   const float* bias, float* out, int64_t m,
                                   int input_size, int g, void* stream);
 
 /* ---- introspection -------------------------------------------------------*/
-int ddd_set_kernel(ddd_model* model, int kernel_kind);
+DDD_API int ddd_set_kernel(ddd_model* model, int kernel_kind);
 /* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256", "generic",
  * "stream_fixed" (fixed stencils, one launch per substep) or "spectral_f64":
  * the kernel family and workgroup geometry of the most recent launch on this
  * handle (the automatic choice depends on the batch size and launch mode). */
-const char* ddd_kernel_name(const ddd_model* model);
+DDD_API const char* ddd_kernel_name(const ddd_model* model);
 /* Algorithmic multiply-adds per grid point per right-hand-side evaluation
  * (SURVEY.md section 8(d)); 2x this is the FLOP count used for the roofline. */
-int64_t ddd_fma_per_point(const ddd_model* model);
+DDD_API int64_t ddd_fma_per_point(const ddd_model* model);
 /* Number of right-hand-side evaluations per step of a scheme. */
-int ddd_scheme_stages(int scheme);
+DDD_API int ddd_scheme_stages(int scheme);
 /* Runs tiny MFMA probes on the current device and checks the operand/result
  * register layouts the kernels assume; 0 = layouts as assumed. */
-int ddd_selftest_mfma_layout(void);
-int ddd_abi_version(void);
-const char* ddd_last_error(void);
+DDD_API int ddd_selftest_mfma_layout(void);
+DDD_API int ddd_abi_version(void);
+DDD_API const char* ddd_last_error(void);
 
 #ifdef __cplusplus
 }

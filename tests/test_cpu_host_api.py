@@ -31,9 +31,17 @@ def test_library_exports_every_declared_symbol():
   assert sorted(_lib.SIGNATURES) == declared
   out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIBRARY_PATH],
                        capture_output=True, text=True, check=True).stdout
-  exported = set(re.findall(r' T (ddd_[a-z0-9_]+)', out))
-  # product ABI == the header: no profiling / debug entry points ride along
-  # (those live in libddd1d_probe.so, __graft_entry__.build_probe)
+  # the ENTIRE defined dynamic symbol table (any type letter), not only ` T ddd_*`:
+  # product ABI == the header.  No profiling / debug entry points (those live in
+  # libddd1d_probe.so, __graft_entry__.build_probe), no C++ host launchers
+  # (ddd::launch::*), no __device_stub__ symbols (-fvisibility=hidden + DDD_API).
+  exported = set()
+  for row in out.splitlines():
+    parts = row.split()
+    if parts:
+      exported.add(parts[-1])
+  # (linker-defined section markers some toolchains add to every shared object)
+  exported -= {'_init', '_fini', '_edata', '_end', '__bss_start'}
   assert exported == set(declared), sorted(exported ^ set(declared))
   assert not hasattr(lib, 'ddd_debug_set_option')
   with pytest.raises(_lib.DDDError, match='probe'):
