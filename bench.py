@@ -76,7 +76,7 @@ TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.
 
 
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
-                'stream_fixed', 'differentiator_b1', 'adaptive_rk23')
+                'rk_substep_external', 'stream_fixed', 'differentiator_b1', 'adaptive_rk23')
 
 
 def parse_args(argv=None):
@@ -530,6 +530,123 @@ def _fixed_step_config(args, lib, world, name, note, batch, unique=None, **overr
   return name, out
 
 
+def load_rk_driver():
+  """examples/librk_driver.so (gcc, against include/ddd1d.h only): the caller-owned
+  midpoint loop over ddd_rk_substep, in C."""
+  import ctypes
+  import ddd1d_amd
+  ddd1d_amd._lib.load_library()
+  lib = ctypes.CDLL(os.path.join(ROOT, 'examples', 'librk_driver.so'))
+  V = ctypes.c_void_p
+  lib.rk_driver_midpoint.restype = ctypes.c_int
+  lib.rk_driver_midpoint.argtypes = [V, ctypes.c_int, ctypes.c_double, ctypes.c_double, V, V, V,
+                                     ctypes.c_int, V, ctypes.c_int, ctypes.POINTER(V)]
+  return lib
+
+
+def _external_driver_config(args):
+  """The section-8(b) seam as an EXTERNAL driver sees it: a host loop that owns the
+  Runge-Kutta stages (integrate.py:143-169 calls the right-hand side per stage) and
+  calls ddd_rk_substep twice per midpoint step.  Three drivers per batch size: the
+  loop in Python inside ddd_stream_fork .. ddd_stream_join (two half-ensemble
+  chains alive across the calls), the same loop in C (examples/rk_driver.c; takes
+  Python out), and the Python loop WITHOUT the bracket (one launch per call on the
+  caller's stream: what the seam gave before)."""
+  import ctypes
+  import torch
+  import ddd1d_amd
+  driver = load_rk_driver()
+  lib = ddd1d_amd._lib.load_library()
+  steps = 200
+  out = {}
+  for batch in (4096, 8192):
+    a = _variant(args)
+    eq, model, _, y0_host = build_workload(a, 0, batch, unique=4096)
+    n = eq.grid.solution_num_points
+    dt = eq.time_step
+    h = np.float32(dt)
+    y0 = torch.from_numpy(y0_host).cuda()
+    bufs = [torch.empty_like(y0) for _ in range(3)]
+    stream = ddd1d_amd._lib.current_stream()
+
+    def python_loop(chained):
+      y, ystage, ynew = bufs
+      y.copy_(y0)
+      ctx = model.chained_substeps() if chained else None
+      if ctx is not None:
+        ctx.__enter__()
+      try:
+        for step in range(steps):
+          t = step * dt
+          model.rk_substep(t, y, y_base=y, c1=0.5 * h, y_out=ystage)
+          model.rk_substep(t + 0.5 * dt, ystage, acc_in=y, c2=h, acc_out=ynew)
+          y, ynew = ynew, y
+      finally:
+        if ctx is not None:
+          ctx.__exit__(None, None, None)
+      return y
+
+    def c_loop(chained):
+      y, ystage, ynew = bufs
+      y.copy_(y0)
+      final = ctypes.c_void_p()
+      rc = driver.rk_driver_midpoint(model._handle, steps, 0.0, dt, y.data_ptr(),
+                                     ystage.data_ptr(), ynew.data_ptr(), batch, stream,
+                                     1 if chained else 0, ctypes.byref(final))
+      if rc != 0:
+        raise RuntimeError(lib.ddd_last_error().decode())
+      return y if final.value == y.data_ptr() else ynew
+
+    def timed(fn, chained):
+      for _ in range(2):
+        fn(chained)
+      torch.cuda.synchronize()
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      ms, jobs = 0.0, 0
+      wall0 = time.perf_counter()
+      while ms < args.config_timed_ms / 2:
+        e0.record()
+        last = fn(chained)
+        e1.record()
+        torch.cuda.synchronize()
+        ms += e0.elapsed_time(e1)
+        jobs += 1
+      wall = time.perf_counter() - wall0
+      flops = 2.0 * model.fma_per_point * batch * n * 2 * steps * jobs
+      return {'value': batch * n * steps * jobs / (ms * 1e-3), 'us_per_substep_call':
+              ms * 1e3 / (2 * steps * jobs), 'fp32_tflops': flops / (ms * 1e-3) / 1e12,
+              'frac': flops / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 'jobs': jobs,
+              'timed_wall_ms': wall * 1e3, 'finite': bool(torch.isfinite(last).all())}, last
+
+    c_chained, y_c = timed(c_loop, True)
+    y_c = y_c.clone()
+    py_chained, y_py = timed(python_loop, True)
+    same = bool(torch.equal(y_c, y_py))
+    py_plain, y_plain = timed(python_loop, False)
+    same = same and bool(torch.equal(y_c, y_plain))
+    ref = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
+                                launch_mode='per_substep')[0]
+    out['b{}'.format(batch)] = {
+        'c_loop_chained': c_chained, 'python_loop_chained': py_chained,
+        'python_loop_unchained': py_plain,
+        'drivers_bit_identical': same,
+        'equals_ddd_integrate_fixed_per_substep': bool(torch.equal(y_c, ref)),
+    }
+    model.close()
+  best = out['b4096']['c_loop_chained']
+  result = {
+      'workload': 'headline model (Burgers N=64 conv-net stencils), midpoint, a HOST loop that owns '
+                  'the RK stages: 2 ddd_rk_substep calls per step, {} steps per job, batch 4096 '
+                  'and 8192 (tiled from 4096 distinct samples); value = the C loop inside '
+                  'ddd_stream_fork .. ddd_stream_join at batch 4096'.format(steps),
+      'value': best['value'], 'unit': 'grid-point-steps/s', 'bound': 'mfma',
+      'achieved': best['fp32_tflops'], 'peak': PEAK_FP32_TFLOPS, 'roofline_unit': 'TFLOP/s',
+      'frac': best['frac'], 'finite': best['finite'], 'kernel': 'mfma_f32_r64',
+  }
+  result.update(out)
+  return 'rk_substep_external', result
+
+
 def _differentiator_config(args):
   """Batch-1 `SavedModelDifferentiator.__call__(t, y)` (integrate.py:48-71) as
   SciPy calls it: host float64 array in, host array out, one launch per call.
@@ -667,6 +784,8 @@ def extra_configs(args, lib, world):
           'stages fused, state through HBM once per step): for callers that need the host '
           'between steps but not between substeps', 4096,
           **dict(base, launch_mode='per_step', steps=200))
+    elif name == 'rk_substep_external':
+      key, val = _external_driver_config(_variant(args, **base))
     elif name == 'stream_fixed':
       key, val = _fixed_step_config(
           args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '

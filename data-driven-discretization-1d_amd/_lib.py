@@ -85,6 +85,8 @@ SIGNATURES = {
     'ddd_rk_substep': (ctypes.c_int, [_V, ctypes.c_double, _V, _V,
                                       ctypes.c_float, _V, _V, ctypes.c_float,
                                       _V, ctypes.c_int, _V]),
+    'ddd_stream_fork': (ctypes.c_int, [_V, _V]),
+    'ddd_stream_join': (ctypes.c_int, [_V, _V]),
     'ddd_integrate_fixed': (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_double,
                                            ctypes.c_int, ctypes.c_int, _V, _V,

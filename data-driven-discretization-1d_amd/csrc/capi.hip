@@ -193,6 +193,15 @@ struct ddd_model {
   // steady state (ddd_integrate_fixed)
   hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+  // ddd_stream_fork .. ddd_stream_join: the same two chains kept alive ACROSS
+  // ddd_rk_substep / ddd_time_derivative calls of a caller that owns the RK loop
+  struct Chain {
+    bool open = false;        // between ddd_stream_fork and ddd_stream_join
+    bool forked = false;      // the internal streams are running ahead of `stream`
+    hipStream_t stream = nullptr;
+    int batch = 0, halves = 1;
+    int half_batch[4] = {0, 0, 0, 0}, slab_first[4] = {0, 0, 0, 0};
+  } chain;
   // output times of ddd_integrate_adaptive_f64
   double* d_times = nullptr;
   size_t times_capacity = 0;
@@ -801,6 +810,132 @@ int check_integrate_args(const ddd_model* m, int n_steps, int save_every,
   return DDD_OK;
 }
 
+// Large ensembles on the per-equation MFMA kernels are advanced as TWO
+// half-ensembles (contiguous sample slabs, independent of each other) on two
+// internal streams, each launch sized to half the machine: while one half is at
+// a kernel boundary (drain, dispatch, 29 KB of weights per wavefront before the
+// first MFMA) the other half's wavefronts have the matrix pipes to themselves,
+// which a single wavefront per SIMD nearly saturates.  Still one fused launch per
+// substep for every sample; results are bit-identical (same kernel, same
+// arithmetic).  Used by ddd_integrate_fixed (per-substep / per-step modes) and,
+// across calls, by ddd_rk_substep / ddd_time_derivative inside a
+// ddd_stream_fork .. ddd_stream_join region.
+constexpr int kMaxParts = 4;
+struct SlabPlan {
+  int halves = 1;                                 // slabs advanced side by side
+  int half_batch[kMaxParts] = {0, 0, 0, 0};
+  int slab_first[kMaxParts] = {0, 0, 0, 0};       // first sample of each slab
+};
+
+SlabPlan plan_slabs(const ddd_model* m, int batch) {
+  SlabPlan plan;
+  plan.half_batch[0] = batch;
+  if (m->kernel != DDD_KERNEL_MFMA || m->explicit_kernel || g_debug.no_spec) return plan;
+  const MfmaGeometry geo = mfma_geometry(m, batch);
+  const int spg = geo.rows / m->dp.N;
+  const int groups = (batch + spg - 1) / spg;
+  const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
+  if (geo.wave_rows != 64 || spec_equation(m, geo.rows) < 0 || groups < 2 * capacity) return plan;
+  plan.halves = 2;
+  if (g_debug.substep_parts > 0) plan.halves = std::min(g_debug.substep_parts, kMaxParts);
+  const int per = ((groups + plan.halves - 1) / plan.halves) * spg;   // whole workgroups
+  int first = 0;
+  for (int i = 0; i < plan.halves; ++i) {
+    plan.slab_first[i] = first;
+    plan.half_batch[i] = std::max(0, std::min(per, batch - first));
+    first += plan.half_batch[i];
+  }
+  return plan;
+}
+
+// The internal streams start after everything already enqueued on `stream` ...
+int fork_lanes(ddd_model* m, hipStream_t stream, int halves) {
+  for (int i = 0; i < halves; ++i) {
+    if (m->aux_stream[i] == nullptr)
+      DDD_HIP(hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking));
+    if (m->ev_join[i] == nullptr)
+      DDD_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+  }
+  if (m->ev_fork == nullptr)
+    DDD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+  DDD_HIP(hipEventRecord(m->ev_fork, stream));
+  for (int i = 0; i < halves; ++i) DDD_HIP(hipStreamWaitEvent(m->aux_stream[i], m->ev_fork, 0));
+  // (No start offset between the chains: whatever it is, they settle into the
+  // same steady state within a few launches -- measured 0 .. 1.75 half-launches,
+  // 72.4 +- 0.1 % throughout, profiles/r3_ablation.txt.)
+  return DDD_OK;
+}
+
+// ... and `stream` continues after everything enqueued on them.  Never skipped: an
+// error inside a forked region still joins before it is reported.
+int join_lanes(ddd_model* m, hipStream_t stream, int halves) {
+  for (int i = 0; i < halves; ++i) {
+    DDD_HIP(hipEventRecord(m->ev_join[i], m->aux_stream[i]));
+    DDD_HIP(hipStreamWaitEvent(stream, m->ev_join[i], 0));
+  }
+  return DDD_OK;
+}
+
+// Entry points other than ddd_rk_substep / ddd_time_derivative end a caller's
+// chained region (ddd_stream_fork) before they touch the model: its stream then
+// sees every substep enqueued so far.
+int chain_close(ddd_model* m) {
+  int rc = DDD_OK;
+  if (m->chain.open && m->chain.forked && m->chain.halves > 1)
+    rc = join_lanes(m, m->chain.stream, m->chain.halves);
+  m->chain.open = false;
+  m->chain.forked = false;
+  return rc;
+}
+
+// One substep of a caller-owned Runge-Kutta loop.  Outside a chained region: one
+// launch on the caller's stream.  Inside (same stream): slab i of this call is
+// ordered after slab i of the previous call only -- the two half-ensemble chains
+// of ddd_integrate_fixed, kept alive across calls.
+int substep_entry(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
+  ddd_model::Chain& ch = m->chain;
+  if (!ch.open || stream != ch.stream || a.derivs_out != nullptr || a.coeffs_out != nullptr)
+    return launch_substep(m, a, stream);
+  if (!ch.forked || ch.batch != a.batch) {
+    if (ch.forked && ch.halves > 1) {   // another batch: other slabs, so join first
+      int rc = join_lanes(m, stream, ch.halves);
+      if (rc) return rc;
+    }
+    const SlabPlan plan = plan_slabs(m, a.batch);
+    ch.batch = a.batch;
+    ch.halves = plan.halves;
+    for (int i = 0; i < kMaxParts; ++i) {
+      ch.half_batch[i] = plan.half_batch[i];
+      ch.slab_first[i] = plan.slab_first[i];
+    }
+    ch.forked = true;
+    if (ch.halves > 1) {
+      int rc = fork_lanes(m, stream, ch.halves);
+      if (rc) { ch.forked = false; return rc; }
+    }
+  }
+  if (ch.halves <= 1) return launch_substep(m, a, stream);
+  int rc = DDD_OK;
+  for (int hf = 0; hf < ch.halves && rc == DDD_OK; ++hf) {
+    if (ch.half_batch[hf] == 0) continue;
+    const size_t off = (size_t)ch.slab_first[hf] * m->dp.N;
+    ddd::SubstepArgs h = a;
+    h.batch = ch.half_batch[hf];
+    h.y_in = a.y_in + off;
+    if (a.y_base != nullptr) h.y_base = a.y_base + off;
+    if (a.y_out != nullptr) h.y_out = a.y_out + off;
+    if (a.acc_in != nullptr) h.acc_in = a.acc_in + off;
+    if (a.acc_out != nullptr) h.acc_out = a.acc_out + off;
+    rc = launch_substep(m, h, m->aux_stream[hf], ch.slab_first[hf], ch.halves);
+  }
+  m->last_batch = a.batch;
+  if (rc) {   // do not leave the internal streams running ahead of a failed call
+    (void)join_lanes(m, stream, ch.halves);
+    ch.forked = false;
+  }
+  return rc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1107,6 +1242,7 @@ int ddd_rk_substep_f64(ddd_model* m, double t, const double* y_in, const double*
 
 int ddd_model_destroy(ddd_model* m) {
   if (m == nullptr) return DDD_OK;
+  (void)chain_close(m);   // the caller's stream sees every substep before the buffers go
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
@@ -1126,6 +1262,7 @@ int ddd_model_destroy(ddd_model* m) {
 }
 
 int ddd_clear_forcing(ddd_model* m) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
   free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
@@ -1230,7 +1367,7 @@ int ddd_time_derivative(ddd_model* m, double t, const float* y, float* dydt, int
   if (batch > 0 && (!y || !dydt)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
   ddd::SubstepArgs a{};
   a.t = t; a.y_in = y; a.c1 = 1.0f; a.y_out = dydt; a.batch = batch;
-  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+  return substep_entry(m, a, static_cast<hipStream_t>(stream));
 }
 
 int ddd_rk_substep(ddd_model* m, double t, const float* y_in, const float* y_base,
@@ -1244,11 +1381,32 @@ int ddd_rk_substep(ddd_model* m, double t, const float* y_in, const float* y_bas
   ddd::SubstepArgs a{};
   a.t = t; a.y_in = y_in; a.y_base = y_base; a.c1 = c1; a.y_out = y_out;
   a.acc_in = acc_in; a.c2 = c2; a.acc_out = acc_out; a.batch = batch;
-  return launch_substep(m, a, static_cast<hipStream_t>(stream));
+  return substep_entry(m, a, static_cast<hipStream_t>(stream));
+}
+
+int ddd_stream_fork(ddd_model* m, void* stream) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (m->spectral)
+    return fail(DDD_ERR_UNSUPPORTED, "spectral models have no chained substeps");
+  int rc = chain_close(m);   // a region that is still open ends here
+  if (rc) return rc;
+  m->chain.open = true;
+  m->chain.stream = static_cast<hipStream_t>(stream);
+  return DDD_OK;
+}
+
+int ddd_stream_join(ddd_model* m, void* stream) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (!m->chain.open) return DDD_OK;
+  if (static_cast<hipStream_t>(stream) != m->chain.stream)
+    return fail(DDD_ERR_INVALID_ARGUMENT,
+                "ddd_stream_join: not the stream the region was opened on (ddd_stream_fork)");
+  return chain_close(m);
 }
 
 int ddd_space_derivatives(ddd_model* m, const float* y, float* out, int batch,
                           void* stream) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   int rc = check_batch(m, batch);
   if (rc) return rc;
   if (batch > 0 && (!y || !out)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
@@ -1261,6 +1419,7 @@ int ddd_space_derivatives(ddd_model* m, const float* y, float* out, int batch,
 }
 
 int ddd_coefficients(ddd_model* m, const float* y, float* out, int batch, void* stream) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   int rc = check_batch(m, batch);
   if (rc) return rc;
   if (batch > 0 && (!y || !out)) return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
@@ -1274,6 +1433,7 @@ int ddd_coefficients(ddd_model* m, const float* y, float* out, int batch, void* 
 int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, double dt,
                         int n_steps, int save_every, const float* y0, float* y_out,
                         int batch, void* stream_) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   int rc = check_integrate_args(m, n_steps, save_every, y0, y_out, batch);
   if (rc) return rc;
   ddd::Tableau tab;
@@ -1299,54 +1459,22 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   float* ystage = m->d_scratch + 2 * elems;
   const float h = (float)dt;
 
-  // Large ensembles on the per-equation MFMA kernels are advanced as TWO
-  // half-ensembles (contiguous sample slabs, independent of each other) on two
-  // internal streams, each launch sized to half the machine and the second
-  // chain started half a substep late: while one half is at a kernel boundary
-  // (drain, dispatch, 29 KB of weights per wavefront before the first MFMA) the
-  // other half's wavefronts have the matrix pipes to themselves, which a single
-  // wavefront per SIMD nearly saturates.  Still one fused launch per substep for
-  // every sample; results are bit-identical (same kernel, same arithmetic).
-  constexpr int kMaxParts = 4;
-  int halves = 1;                                  // slabs advanced side by side
-  int half_batch[kMaxParts] = {batch, 0, 0, 0};
-  int slab_first[kMaxParts] = {0, 0, 0, 0};        // first sample of each slab
+  // large ensembles: two half-ensembles side by side (plan_slabs)
+  const SlabPlan plan = plan_slabs(m, batch);
+  const int halves = plan.halves;
+  const int* half_batch = plan.half_batch;
+  const int* slab_first = plan.slab_first;
   int step_eq = -1;   // per-equation kernel for DDD_LAUNCH_PER_STEP
   if (m->kernel == DDD_KERNEL_MFMA && !m->explicit_kernel && !g_debug.no_spec) {
     const MfmaGeometry geo = mfma_geometry(m, batch);
-    const int spg = geo.rows / m->dp.N;
-    const int groups = (batch + spg - 1) / spg;
-    const int capacity = geo.rows == 64 ? 2 * device_simds() : device_simds() / 2;
     if (geo.wave_rows == 64 && launch_mode == DDD_LAUNCH_PER_STEP)
       step_eq = spec_equation(m, geo.rows);
-    if (geo.wave_rows == 64 && spec_equation(m, geo.rows) >= 0 && groups >= 2 * capacity) {
-      halves = 2;
-      if (g_debug.substep_parts > 0) halves = std::min(g_debug.substep_parts, kMaxParts);
-      const int per = ((groups + halves - 1) / halves) * spg;   // whole workgroups
-      int first = 0;
-      for (int i = 0; i < halves; ++i) {
-        slab_first[i] = first;
-        half_batch[i] = std::max(0, std::min(per, batch - first));
-        first += half_batch[i];
-      }
-    }
   }
   hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
   if (halves > 1) {
-    for (int i = 0; i < halves; ++i) {
-      if (m->aux_stream[i] == nullptr)
-        DDD_HIP(hipStreamCreateWithFlags(&m->aux_stream[i], hipStreamNonBlocking));
-      if (m->ev_join[i] == nullptr)
-        DDD_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
-      lanes[i] = m->aux_stream[i];
-    }
-    if (m->ev_fork == nullptr)
-      DDD_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    DDD_HIP(hipEventRecord(m->ev_fork, stream));
-    for (int i = 0; i < halves; ++i) DDD_HIP(hipStreamWaitEvent(lanes[i], m->ev_fork, 0));
-    // (No start offset between the chains: whatever it is, they settle into the
-    // same steady state within a few launches -- measured 0 .. 1.75 half-launches,
-    // 72.4 +- 0.1 % throughout, profiles/r3_ablation.txt.)
+    rc = fork_lanes(m, stream, halves);
+    if (rc) return rc;
+    for (int i = 0; i < halves; ++i) lanes[i] = m->aux_stream[i];
   }
   size_t half_off[kMaxParts];
   for (int i = 0; i < kMaxParts; ++i) half_off[i] = (size_t)slab_first[i] * m->dp.N;
@@ -1387,7 +1515,10 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
           default: break;
         }
       }
-      DDD_HIP(hipGetLastError());
+      if (hipGetLastError() != hipSuccess) {
+        rc = fail(DDD_ERR_HIP, "step launch failed");
+        break;
+      }
       m->last_launch_streamed = false;
       y = ynew;
       if (saving) ++snap;
@@ -1416,26 +1547,27 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
         a.trace_row0 = walk_launch++ * ddd::kWalkTraceRows;
 #endif
         rc = launch_substep(m, a, lanes[hf], slab_first[hf], halves);
-        if (rc) return rc;
+        if (rc) break;
       }
+      if (rc) break;
       if (accumulate) acc = ynew;
     }
+    if (rc) break;   // (the join below still runs: the internal streams may be busy)
     y = ynew;
     if (saving) ++snap;
   }
   if (halves > 1) {
-    for (int i = 0; i < halves; ++i) {
-      DDD_HIP(hipEventRecord(m->ev_join[i], lanes[i]));
-      DDD_HIP(hipStreamWaitEvent(stream, m->ev_join[i], 0));
-    }
+    const int rc_join = join_lanes(m, stream, halves);
+    if (rc == DDD_OK) rc = rc_join;
     m->last_batch = batch;
   }
-  return DDD_OK;
+  return rc;
 }
 
 int ddd_integrate_fixed_f64(ddd_model* m, int scheme, double t0, double dt, int n_steps,
                             int save_every, const double* y0, double* y_out, int batch,
                             void* stream) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   if (m != nullptr && m->spectral) {
     // float64 state AND right-hand side, one fused launch per substep
     if (batch < 0 || n_steps < 0 || save_every < 1)
@@ -1498,7 +1630,9 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
                                const double* y0, double* y_out, int32_t* nfev,
                                int32_t* status, int batch, void* stream_) {
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
-  int rc = check_batch(m, batch, m->spectral);
+  int rc = chain_close(m);
+  if (rc) return rc;
+  rc = check_batch(m, batch, m->spectral);
   if (rc) return rc;
   if (times == nullptr || n_times < 1)
     return fail(DDD_ERR_INVALID_ARGUMENT, "times must hold at least one value");
@@ -1712,6 +1846,7 @@ int ddd_polynomial_accuracy_apply(const float* inputs, const float* nullspace,
 }
 
 int ddd_set_kernel(ddd_model* m, int kind) {
+  if (m != nullptr) { int rcj = chain_close(m); if (rcj) return rcj; }
   if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
   if (m->spectral) return fail(DDD_ERR_UNSUPPORTED, "spectral models have one kernel");
   switch (kind) {

@@ -19,6 +19,7 @@ null-space bases and biases are stored with them because the SVD basis is not
 unique across LAPACK builds (polynomials.py:246-254).
 """
 import ctypes
+import contextlib
 import json
 import os
 from typing import List, Optional, Sequence
@@ -287,6 +288,22 @@ class _DeviceModel(object):
         self._handle, float(t), y_in.data_ptr(), ptr(y_base), float(c1),
         ptr(y_out), ptr(acc_in), float(c2), ptr(acc_out), y_in.shape[0],
         _lib.current_stream()))
+
+  @contextlib.contextmanager
+  def chained_substeps(self):
+    """`with model.chained_substeps(): ...` around a caller-owned Runge-Kutta loop
+    of rk_substep / time_derivative_rows calls on the current stream
+    (ddd_stream_fork .. ddd_stream_join, include/ddd1d.h): large ensembles then
+    advance as two half-ensemble chains that stay alive across the calls.  Inside
+    the block the arrays handed to those calls must not be touched by anything
+    else; after it the current stream is ordered behind every substep."""
+    lib = _lib.load_library()
+    stream = _lib.current_stream()
+    _lib.check(lib.ddd_stream_fork(self._handle, stream))
+    try:
+      yield self
+    finally:
+      _lib.check(lib.ddd_stream_join(self._handle, stream))
 
   def integrate_fixed(self, y0, num_steps: int, dt: Optional[float] = None,
                       t0: float = 0.0, scheme: str = 'midpoint',

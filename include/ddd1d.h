@@ -239,6 +239,32 @@ DDD_API int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
                    const float* acc_in, float c2, float* acc_out, int batch,
                    void* stream);
 
+/* A caller that owns the Runge-Kutta loop -- the shape of integrate.odeint
+ * (integrate.py:143-169: the driver calls the right-hand side once per stage) --
+ * gets the library's own per-substep throughput by bracketing its loop:
+ *
+ *     ddd_stream_fork(model, stream);
+ *     for (...) { ddd_rk_substep(model, ..., stream); ddd_rk_substep(model, ..., stream); }
+ *     ddd_stream_join(model, stream);
+ *
+ * Inside the region, ddd_rk_substep / ddd_time_derivative calls on `stream`
+ * advance a large ensemble as two contiguous half-ensembles on two internal
+ * streams: half i of a call is ordered after everything enqueued on `stream`
+ * before ddd_stream_fork and after half i of the previous call -- NOT after the
+ * other half, so one half's launch boundary overlaps the other half's
+ * evaluation.  Samples are independent, so results are bit-identical to the
+ * unbracketed calls.  Contract inside the region: the arrays handed to these
+ * calls are touched by nothing else (no other work on `stream` reads or writes
+ * them, the host does not read them) until ddd_stream_join, after which `stream`
+ * is ordered behind every substep enqueued.  Any other entry point taking this
+ * model (and ddd_model_destroy) joins first, so a forgotten join cannot outlive
+ * the model; calls on another stream, a batch too small to split, and models
+ * without a per-equation MFMA kernel simply run on `stream` as without the
+ * region.  ddd_stream_join without an open region is a no-op.  Neither call
+ * synchronises the host. */
+DDD_API int ddd_stream_fork(ddd_model* model, void* stream);
+DDD_API int ddd_stream_join(ddd_model* model, void* stream);
+
 /* Replaces: model.integrate_ode (model.py:138-159) and, with the controller
  * pinned at max_step, the solve_ivp loop of integrate.odeint
  * (integrate.py:154-155) -- for the whole batch at once.

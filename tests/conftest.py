@@ -28,6 +28,7 @@ def built_artifacts():
   try:
     entry.build_hip()
     entry.build_oracle()
+    entry.build_examples()
   except (RuntimeError, OSError, subprocess.CalledProcessError) as exc:   # no hipcc / make here
     print('conftest: could not build native artifacts: {}'.format(exc))
 

@@ -3,6 +3,7 @@ import numpy as np
 import pytest
 
 from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err)
+import ddd1d_amd
 from ddd1d_amd import equations, integrate, model as model_lib
 
 pytestmark = pytest.mark.gpu
@@ -157,6 +158,79 @@ def test_rk_substep_composes_midpoint():
   acc = torch.empty_like(y0)
   model.rk_substep(dt / 2, ymid, acc_in=y0, c2=dt, acc_out=acc)
   np.testing.assert_array_equal(acc.cpu().numpy(), want.cpu().numpy())
+
+
+@pytest.mark.parametrize('equation,num_points,batch', [
+    ('burgers', 64, 4100),    # >= 4096 groups: two half-ensemble chains across the calls
+    ('burgers', 64, 8200),
+    ('kdv', 32, 8300),        # two samples per group
+    ('burgers', 64, 300),     # too small to split: the bracket changes nothing
+])
+def test_external_rk_loop_inside_fork_join(equation, num_points, batch):
+  """A caller that owns the RK loop (the shape of integrate.odeint, integrate.py:143-169):
+  ddd_rk_substep twice per midpoint step inside ddd_stream_fork .. ddd_stream_join, written
+  in Python and in C (examples/rk_driver.c).  Bit-identical to the unbracketed loop, to
+  ddd_integrate_fixed in every launch mode, and a sub-sample against the oracle."""
+  import ctypes
+  import torch
+  import bench
+  driver = bench.load_rk_driver()
+  model = make_model(equation, True, num_points=num_points, resample_factor=2)
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  if forcing is not None:
+    model.set_forcing(forcing)
+  y0_host = random_phase_ic(model.equation, batch)
+  y0 = torch.from_numpy(y0_host).cuda()
+  dt = model.equation.time_step
+  h = np.float32(dt)
+  steps = 7
+
+  def python_loop(chained):
+    y, ystage, ynew = y0.clone(), torch.empty_like(y0), torch.empty_like(y0)
+    ctx = model.chained_substeps() if chained else None
+    if ctx is not None:
+      ctx.__enter__()
+    for step in range(steps):
+      t = step * dt
+      model.rk_substep(t, y, y_base=y, c1=0.5 * h, y_out=ystage)
+      model.rk_substep(t + 0.5 * dt, ystage, acc_in=y, c2=h, acc_out=ynew)
+      y, ynew = ynew, y
+    if ctx is not None:
+      ctx.__exit__(None, None, None)
+    return y.cpu().numpy()   # (a copy on the caller's stream: ordered behind the join)
+
+  def c_loop(chained):
+    y, ystage, ynew = y0.clone(), torch.empty_like(y0), torch.empty_like(y0)
+    final = ctypes.c_void_p()
+    rc = driver.rk_driver_midpoint(model._handle, steps, 0.0, dt, y.data_ptr(),
+                                   ystage.data_ptr(), ynew.data_ptr(), batch,
+                                   ddd1d_amd._lib.current_stream(), int(chained),
+                                   ctypes.byref(final))
+    assert rc == 0
+    return (y if final.value == y.data_ptr() else ynew).cpu().numpy()
+
+  want = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
+                               launch_mode='persistent')[0].cpu().numpy()
+  for got in (python_loop(False), python_loop(True), c_loop(True), c_loop(False)):
+    np.testing.assert_array_equal(got, want)
+  # the bracket survives entry points that join on their own, and an unmatched join
+  lib = ddd1d_amd._lib.load_library()
+  stream = ddd1d_amd._lib.current_stream()
+  assert lib.ddd_stream_join(model._handle, stream) == 0
+  assert lib.ddd_stream_fork(model._handle, stream) == 0
+  ymid = torch.empty_like(y0)
+  model.rk_substep(0.0, y0, y_base=y0, c1=0.5 * h, y_out=ymid)
+  again = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
+                                launch_mode='per_substep')[0].cpu().numpy()   # joins first
+  np.testing.assert_array_equal(again, want)
+  ymid_plain = torch.empty_like(y0)   # the region is closed now: a plain launch
+  model.rk_substep(0.0, y0, y_base=y0, c1=0.5 * h, y_out=ymid_plain)
+  np.testing.assert_array_equal(ymid.cpu().numpy(), ymid_plain.cpu().numpy())
+  rows = np.array([0, batch // 2, batch - 1])
+  sub_forcing = None if forcing is None else {k: v[rows] for k, v in forcing.items()}
+  ref = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps, steps,
+                               y0_host[rows], forcing=sub_forcing)
+  assert rel_err(want[rows], ref[0]) < TOL
 
 
 def test_float64_state():
