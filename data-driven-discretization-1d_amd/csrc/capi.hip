@@ -202,10 +202,19 @@ struct ddd_model {
     int batch = 0, halves = 1;
     int half_batch[4] = {0, 0, 0, 0}, slab_first[4] = {0, 0, 0, 0};
   } chain;
-  // output times of ddd_integrate_adaptive_f64
-  double* d_times = nullptr;
-  size_t times_capacity = 0;
-  std::vector<double> h_times;       // staging copy that outlives the asynchronous upload
+  // output times of ddd_integrate_adaptive_f64: a small ring of (page-locked host
+  // copy, device copy) pairs, each released by an event recorded behind the launch
+  // that reads it -- the entry point only enqueues (no host synchronisation unless
+  // kTimeSlots calls are still in flight), on whatever stream each call names
+  static constexpr int kTimeSlots = 4;
+  struct TimeSlot {
+    double* host = nullptr;    // hipHostMalloc
+    double* dev = nullptr;
+    size_t capacity = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+  } time_slot[kTimeSlots];
+  int next_time_slot = 0;
   // scratch for the per-substep launch mode
   float* d_scratch = nullptr;
   size_t scratch_floats = 0;
@@ -318,14 +327,23 @@ std::vector<float> quad_rows(const float* rows64, int rows) {
   return out;
 }
 
+// Natural-layout description of the net the MFMA packing reads: the model's own
+// ([K][cin][cout] + bias per layer, DevParams::w_off / b_off) or its zero-padded
+// 5-tap x 32-channel embedding (embed_small_tower).
+struct NetLayout {
+  const float* weights;
+  int w_off[ddd::kMaxLayers], b_off[ddd::kMaxLayers];
+};
+
 // Reorder conv weights into MFMA A-operand order (rhs_mfma.h).
-int pack_mfma_weights(ddd_model* m, const float* weights) {
+int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
   const ddd::DevParams& dp = m->dp;
+  const float* weights = net.weights;
   const int hidden = dp.L - 2;
   {
     // input layer 1 -> 32: k = 2 s + (lane >> 5) is the tap, k = 5 the bias
-    const float* w = weights + dp.w_off[0];   // [5][1][32]
-    const float* b = weights + dp.b_off[0];
+    const float* w = weights + net.w_off[0];   // [5][1][32]
+    const float* b = weights + net.b_off[0];
     std::vector<float> packed((size_t)ddd::mfma::kInSteps * 64, 0.0f);
     for (int s = 0; s < ddd::mfma::kInSteps; ++s)
       for (int lane = 0; lane < 64; ++lane) {
@@ -339,8 +357,8 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
   if (hidden > 0) {
     std::vector<float> packed((size_t)hidden * ddd::mfma::kHidSteps * 64, 0.0f);
     for (int h = 0; h < hidden; ++h) {
-      const float* w = weights + dp.w_off[h + 1];   // [5][32][32]
-      const float* b = weights + dp.b_off[h + 1];
+      const float* w = weights + net.w_off[h + 1];   // [5][32][32]
+      const float* b = weights + net.b_off[h + 1];
       float* dst = packed.data() + (size_t)h * ddd::mfma::kHidSteps * 64;
       for (int s = 0; s < 80; ++s) {
         const int tap = s / 16, jj = s % 16;
@@ -364,8 +382,8 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
   }
   {
     const int l = dp.L - 1;
-    const float* w_nat = weights + dp.w_off[l];   // [5][32][C_out]
-    const float* b_nat = weights + dp.b_off[l];
+    const float* w_nat = weights + net.w_off[l];   // [5][32][C_out]
+    const float* b_nat = weights + net.b_off[l];
     // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
     // W'[tap][cin][G d + g] = sum_j W[tap][cin][start_d + j] * ns_d[j][g]
     // (accumulated in double, rounded once to float32), same for the bias.
@@ -499,6 +517,40 @@ int pack_mfma_weights(ddd_model* m, const float* weights) {
   return DDD_OK;
 }
 
+// Smaller towers ride the 5-tap x 32-channel MFMA layers EXACTLY, embedded with
+// zero weights: a K-tap kernel (K < 5) is the 5-tap kernel whose outer taps are
+// zero (tap k of K sits at offset k - ceil((K-1)/2), the alignment of
+// layers.pad_periodic(center=True), layers.py:76-79), F < 32 filters are 32
+// filters whose extra rows / columns / biases are zero.  fma(0, x, acc) == acc
+// for every finite x, and a padded channel is multiplied by zero weights in the
+// next layer whatever the activation makes of its 0, so the finite results are
+// bit-identical to the unpadded evaluation order-for-order; the matrix work
+// grows by 5/K and (32/F)^2, still an order of magnitude ahead of the generic
+// kernel.  (Algorithmic FLOPs -- ddd_fma_per_point -- keep counting the true net.)
+void embed_small_tower(const ddd::DevParams& dp, const std::vector<float>& wv,
+                       std::vector<float>* padded, NetLayout* net) {
+  const int k5 = ddd::mfma::kKW, f32 = ddd::mfma::kF;
+  const int shift = (k5 - 1) / 2 - dp.K / 2;   // ceil((5-1)/2) - ceil((K-1)/2)
+  padded->clear();
+  for (int l = 0; l < dp.L; ++l) {
+    const int cin = l == 0 ? 1 : f32;
+    const int cout = l == dp.L - 1 ? dp.C_out : f32;
+    net->w_off[l] = (int)padded->size();
+    padded->resize(padded->size() + (size_t)k5 * cin * cout, 0.0f);
+    net->b_off[l] = (int)padded->size();
+    padded->resize(padded->size() + (size_t)cout, 0.0f);
+    const float* w = wv.data() + dp.w_off[l];
+    const float* b = wv.data() + dp.b_off[l];
+    for (int k = 0; k < dp.K; ++k)
+      for (int ci = 0; ci < dp.cin[l]; ++ci)
+        for (int co = 0; co < dp.cout[l]; ++co)
+          (*padded)[(size_t)net->w_off[l] + ((size_t)(k + shift) * cin + ci) * cout + co] =
+              w[((size_t)k * dp.cin[l] + ci) * dp.cout[l] + co];
+    for (int co = 0; co < dp.cout[l]; ++co) (*padded)[(size_t)net->b_off[l] + co] = b[co];
+  }
+  net->weights = padded->data();
+}
+
 void decide_mfma(ddd_model* m) {
   const ddd::DevParams& dp = m->dp;
   char why[256] = "";
@@ -520,8 +572,8 @@ void decide_mfma(ddd_model* m) {
     // no projection) run on the run-time-parameterised MFMA kernels
     if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2) wide = true;
     if (dp.C_out > ddd::kChMax) wide = true;
-    if (dp.F != ddd::mfma::kF) no("filter_size > 32");        // (smaller ones arrive zero-padded)
-    if (dp.K != ddd::mfma::kKW) no("kernel_size > 5");
+    if (dp.F > ddd::mfma::kF) no("filter_size > 32");         // (smaller towers are packed
+    if (dp.K > ddd::mfma::kKW) no("kernel_size > 5");         //  zero-padded: embed_small_tower)
     if (dp.L < 2) no("fewer than 2 conv layers");
     if (dp.C_out > ddd::kChWide) no("more than 24 output channels");
   }
@@ -1041,46 +1093,6 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   }
 
   std::vector<float> wv(weights, weights + n_weights);
-  // Smaller towers ride the 5-tap x 32-channel MFMA layers EXACTLY, embedded
-  // with zero weights: a K-tap kernel (K < 5) is the 5-tap kernel whose outer
-  // taps are zero (tap k of K sits at offset k - ceil((K-1)/2), the alignment of
-  // layers.pad_periodic(center=True), layers.py:76-79), F < 32 filters are 32
-  // filters whose extra rows / columns / biases are zero.  fma(0, x, acc) == acc
-  // for every finite x, and a padded channel is multiplied by zero weights in the
-  // next layer whatever the activation makes of its 0, so the finite results are
-  // bit-identical to the unpadded evaluation order-for-order; the matrix work
-  // grows by 5/K and (32/F)^2, still an order of magnitude ahead of the generic
-  // kernel.  (Algorithmic FLOPs -- ddd_fma_per_point -- keep counting the true net.)
-  if (dp.L >= 2 && dp.K <= ddd::mfma::kKW && dp.F <= ddd::mfma::kF &&
-      (dp.K != ddd::mfma::kKW || dp.F != ddd::mfma::kF)) {
-    const int k5 = ddd::mfma::kKW, f32 = ddd::mfma::kF;
-    const int shift = (k5 - 1) / 2 - dp.K / 2;   // ceil((5-1)/2) - ceil((K-1)/2)
-    std::vector<float> padded;
-    int w_off[ddd::kMaxLayers], b_off[ddd::kMaxLayers], cin[ddd::kMaxLayers], cout[ddd::kMaxLayers];
-    for (int l = 0; l < dp.L; ++l) {
-      cin[l] = l == 0 ? 1 : f32;
-      cout[l] = l == dp.L - 1 ? c_out : f32;
-      w_off[l] = (int)padded.size();
-      padded.resize(padded.size() + (size_t)k5 * cin[l] * cout[l], 0.0f);
-      b_off[l] = (int)padded.size();
-      padded.resize(padded.size() + (size_t)cout[l], 0.0f);
-      const float* w = wv.data() + dp.w_off[l];
-      const float* b = wv.data() + dp.b_off[l];
-      for (int k = 0; k < dp.K; ++k)
-        for (int ci = 0; ci < dp.cin[l]; ++ci)
-          for (int co = 0; co < dp.cout[l]; ++co)
-            padded[(size_t)w_off[l] + ((size_t)(k + shift) * cin[l] + ci) * cout[l] + co] =
-                w[((size_t)k * dp.cin[l] + ci) * dp.cout[l] + co];
-      for (int co = 0; co < dp.cout[l]; ++co) padded[(size_t)b_off[l] + co] = b[co];
-    }
-    for (int l = 0; l < dp.L; ++l) {
-      dp.w_off[l] = w_off[l]; dp.b_off[l] = b_off[l]; dp.cin[l] = cin[l]; dp.cout[l] = cout[l];
-    }
-    dp.K = k5;
-    dp.F = f32;
-    wv.swap(padded);
-    weights = wv.data();
-  }
   rc = upload(wv, &m->d_weights);
   dp.weights = m->d_weights;
   if (!rc) {
@@ -1116,7 +1128,17 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
       rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr,
                                 dp.target == ddd::TARGET_COEFFICIENTS && !projected &&
                                     !fold_shape);
-      if (!rc) rc = pack_mfma_weights(m, weights);
+      if (!rc) {
+        // (the generic kernel keeps the model's own K, F and weights: a model that
+        // falls back to it -- N > 256, ddd_set_kernel(generic) -- never runs the
+        // padded net; only the MFMA packing sees the embedding)
+        std::vector<float> padded;
+        NetLayout net;
+        net.weights = wv.data();
+        for (int l = 0; l < dp.L; ++l) { net.w_off[l] = dp.w_off[l]; net.b_off[l] = dp.b_off[l]; }
+        if (dp.K != ddd::mfma::kKW || dp.F != ddd::mfma::kF) embed_small_tower(dp, wv, &padded, &net);
+        rc = pack_mfma_weights(m, net);
+      }
     }
   }
   if (rc) { ddd_model_destroy(m); return rc; }
@@ -1249,7 +1271,14 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
-  free_dev(m->d_times);
+  for (auto& slot : m->time_slot) {
+    if (slot.done != nullptr) {
+      if (slot.in_flight) (void)hipEventSynchronize(slot.done);
+      (void)hipEventDestroy(slot.done);
+    }
+    if (slot.host != nullptr) (void)hipHostFree(slot.host);
+    free_dev(slot.dev);
+  }
   for (int i = 0; i < 4; ++i) {
     if (m->aux_stream[i] != nullptr) (void)hipStreamDestroy(m->aux_stream[i]);
     if (m->ev_join[i] != nullptr) (void)hipEventDestroy(m->ev_join[i]);
@@ -1643,24 +1672,44 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     return fail(DDD_ERR_INVALID_ARGUMENT, "rtol and max_step must be positive, atol >= 0");
   if (batch > 0 && (!y0 || !y_out || !nfev || !status))
     return fail(DDD_ERR_INVALID_ARGUMENT, "NULL array");
+  if (m->spectral && is_forced_family(m->cfg.equation))
+    return fail(DDD_ERR_UNSUPPORTED,
+                "the spectral adaptive kernel carries no forcing term: Burgers' forcing(t) "
+                "(equations.py:276-277) would be dropped; integrate it with the host driver "
+                "(integrate.odeint over ddd_time_derivative_f64 + finalize_time_derivative)");
   if (batch == 0) return DDD_OK;
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  if (m->times_capacity < (size_t)n_times) {
-    free_dev(m->d_times);
-    m->d_times = nullptr;
-    m->times_capacity = 0;
-    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_times), (size_t)n_times * sizeof(double)));
-    m->times_capacity = (size_t)n_times;
+  // the caller's array may be gone before the copy runs: upload from a page-locked
+  // copy the model owns until the launch that reads it has finished
+  ddd_model::TimeSlot& slot = m->time_slot[m->next_time_slot];
+  m->next_time_slot = (m->next_time_slot + 1) % ddd_model::kTimeSlots;
+  if (slot.in_flight) {   // only when kTimeSlots adaptive calls are still queued
+    DDD_HIP(hipEventSynchronize(slot.done));
+    slot.in_flight = false;
   }
-  // (the caller's array may be gone before the copy runs: upload from a copy the
-  // model owns; an earlier launch that still reads d_times is ordered before it
-  // on the same stream)
-  DDD_HIP(hipStreamSynchronize(stream));
-  m->h_times.assign(times, times + n_times);
-  DDD_HIP(hipMemcpyAsync(m->d_times, m->h_times.data(), (size_t)n_times * sizeof(double),
+  if (slot.capacity < (size_t)n_times) {
+    if (slot.host != nullptr) (void)hipHostFree(slot.host);
+    free_dev(slot.dev);
+    slot.host = nullptr; slot.dev = nullptr; slot.capacity = 0;
+    DDD_HIP(hipHostMalloc(reinterpret_cast<void**>(&slot.host), (size_t)n_times * sizeof(double),
+                          hipHostMallocDefault));
+    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&slot.dev), (size_t)n_times * sizeof(double)));
+    slot.capacity = (size_t)n_times;
+  }
+  if (slot.done == nullptr)
+    DDD_HIP(hipEventCreateWithFlags(&slot.done, hipEventDisableTiming));
+  std::memcpy(slot.host, times, (size_t)n_times * sizeof(double));
+  DDD_HIP(hipMemcpyAsync(slot.dev, slot.host, (size_t)n_times * sizeof(double),
                          hipMemcpyHostToDevice, stream));
   ddd::AdaptiveArgs a{};
-  a.times = m->d_times; a.n_times = n_times;
+  // the slot is free again once the launch enqueued below has run
+  const auto enqueued = [&]() -> int {
+    DDD_HIP(hipGetLastError());
+    DDD_HIP(hipEventRecord(slot.done, stream));
+    slot.in_flight = true;
+    return DDD_OK;
+  };
+  a.times = slot.dev; a.n_times = n_times;
   a.rtol = rtol; a.atol = atol; a.max_step = max_step;
   a.y0 = y0; a.y_out = y_out; a.nfev = nfev; a.status = status; a.batch = batch;
   if (max_attempts <= 0) {
@@ -1688,8 +1737,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     else if (pts <= 4) DDD_SPECTRAL_ADAPTIVE(4);
     else DDD_SPECTRAL_ADAPTIVE(8);
 #undef DDD_SPECTRAL_ADAPTIVE
-    DDD_HIP(hipGetLastError());
-    return DDD_OK;
+    return enqueued();
   }
   if (m->kernel != DDD_KERNEL_MFMA) {
     // generic right-hand side (WENO5 exact solver, nets the MFMA path does not carry):
@@ -1702,8 +1750,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(ddd::generic::adaptive_kernel, dim3(batch), dim3(ddd::generic::kThreads),
                        lds, stream, m->dp, a);
-    DDD_HIP(hipGetLastError());
-    return DDD_OK;
+    return enqueued();
   }
   m->dp.dpp_rol = dpp_wave_rol_ok();
   MfmaGeometry geo = mfma_geometry(m, batch);
@@ -1730,8 +1777,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
         ddd::launch::adaptive_runtime_unit<256>(m->dp, a, blocks, stream);
       }
   }
-  DDD_HIP(hipGetLastError());
-  return DDD_OK;
+  return enqueued();
 }
 
 int ddd_circulant_apply_f64(const double* kernel, const double* in, double* out, int rows,

@@ -39,13 +39,14 @@ def weak_shard_ids(per_rank: int, rank: int):
 def gather_states(local, total: Optional[int] = None, group=None):
   """All-gather per-rank slabs [b_r, ...] into [sum b_r, ...] in rank order.
 
-  Slab sizes are never exchanged: with ``total`` every rank derives them from
-  ``shard_bounds`` (the partition all callers use); without it the slabs are
-  taken to be equal (weak sharding).  Equal slabs use ONE
-  ``all_gather_into_tensor`` and nothing else -- no pickled object collective,
-  no host synchronisation --; ragged slabs (total not divisible by the world
-  size) are padded to the largest slab and trimmed.  Works on any backend
-  (RCCL for CUDA tensors, gloo for CPU tensors).
+  With ``total`` every rank derives the slab sizes from ``shard_bounds`` (the
+  partition all callers use) and nothing is exchanged: equal slabs use ONE
+  ``all_gather_into_tensor`` -- no pickled object collective, no host
+  synchronisation --; ragged slabs (total not divisible by the world size) are
+  padded to the largest slab and trimmed.  Without ``total`` the slab sizes are
+  exchanged first (one all-gather of one int64 per rank, then a host read), so
+  ragged slabs are gathered correctly instead of corrupting an undersized buffer.
+  Works on any backend (RCCL for CUDA tensors, gloo for CPU tensors).
   """
   import torch
   import torch.distributed as dist
@@ -55,7 +56,10 @@ def gather_states(local, total: Optional[int] = None, group=None):
   if world == 1:
     return local
   if total is None:
-    sizes = [int(local.shape[0])] * world
+    mine = torch.tensor([int(local.shape[0])], dtype=torch.int64, device=local.device)
+    everyone = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    sizes = [int(v) for v in everyone.cpu()]
   else:
     bounds = [shard_bounds(total, r, world) for r in range(world)]
     sizes = [hi - lo for lo, hi in bounds]

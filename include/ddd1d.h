@@ -309,7 +309,14 @@ DDD_API int ddd_integrate_fixed_f64(ddd_model* model, int scheme, double t0, dou
  * Burgers solver; nets the MFMA path does not carry) with one workgroup per
  * sample; spectral models (ddd_spectral_create: SpectralDifferentiator, the
  * "exact" KdV / KS solver, integrate.py:108-121) with a float64 right-hand
- * side. */
+ * side.  The spectral kernel carries no forcing term: a spectral model of the
+ * Burgers family (whose finalize_time_derivative adds forcing(t),
+ * equations.py:276-277) returns DDD_ERR_UNSUPPORTED here -- drive it from the host
+ * over ddd_time_derivative_f64, as SpectralDifferentiator.__call__ does.
+ * Enqueue-only: `times` is copied into a model-owned page-locked buffer before the
+ * call returns (a ring of four; the host waits only if four adaptive calls on
+ * this model are still in flight), uploaded and consumed on `stream`.  Not
+ * capturable into a HIP graph (the ring recycles through events). */
 DDD_API int ddd_integrate_adaptive_f64(ddd_model* model, const double* times,
                                int n_times, double rtol, double atol,
                                double max_step, long long max_attempts,

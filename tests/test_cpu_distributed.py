@@ -34,6 +34,9 @@ def _worker(rank, world, port, total, tmpdir):
     final = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0,
                                    1e-3, 3, 3, y0, forcing=forcing)[0]
     gathered = distributed.gather_states(torch.from_numpy(final), total=total)
+    # without `total` the slab sizes are exchanged: ragged slabs still gather in order
+    unsized = distributed.gather_states(torch.from_numpy(final))
+    assert torch.equal(unsized, gathered)
     if rank == 0:
       np.save(os.path.join(tmpdir, 'gathered.npy'), gathered.numpy())
   finally:
