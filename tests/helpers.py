@@ -90,3 +90,38 @@ def baseline_spec(eq, accuracy_order=1):
   spec.update(resample_factor=eq.grid.resample_factor,
               baseline_coefficients=stencils)
   return spec
+
+
+def baseline_rhs_f64(spec, y, t=0.0, forcing=None):
+  """The fixed-stencil / WENO right-hand side evaluated ENTIRELY in float64 from
+  the spec's stencil tables (an independent restatement of integrate.py:85-92 /
+  124-140 over the oracle's dtype-following pieces): periodic correlation with
+  tap k at x + k - ceil((G - 1) / 2) (layers.pad_periodic(center=True)), WENO5
+  reconstructions rolled one cell, equation of motion, forcing.  The distance of
+  the float32 oracle from this is the float32 rounding noise of the formulas
+  themselves on these inputs: the floor under every float32 tolerance."""
+  y = np.asarray(y, dtype=np.float64)
+  cols = []
+  for taps in spec['baseline_coefficients']:
+    taps = np.asarray(taps, dtype=np.float64)
+    left = -(-(len(taps) - 1) // 2)
+    cols.append(sum(taps[k] * np.roll(y, left - k, axis=-1) for k in range(len(taps))))
+  derivs = np.stack(cols, axis=-1)
+  if spec.get('weno'):
+    derivs[..., 0] = np.roll(oracle.weno_reconstruct_left(y), 1, axis=-1)
+    derivs[..., 1] = np.roll(oracle.weno_reconstruct_right(y), 1, axis=-1)
+  out = oracle.equation_of_motion(spec['equation'], y, derivs, spec['eta'], spec['dx'])
+  if spec.get('forced', False) and forcing is not None:
+    out = out + oracle.forcing_f64(t, forcing, spec['num_points'], spec['resample_factor'],
+                                   spec['period'], spec['conservative'])
+  return out
+
+
+def measured_bound(f32_result, f64_truth, base=1e-5, label=''):
+  """max(base, 4 x the distance of the float32 oracle from the float64 evaluation
+  of the same formulas on the same inputs), with that floor printed."""
+  floor = rel_err(f32_result, f64_truth)
+  bound = max(base, 4 * floor)
+  if bound > base:
+    print('{} float32 noise floor {:.1e} -> bound {:.1e}'.format(label, floor, bound))
+  return bound

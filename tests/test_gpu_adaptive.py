@@ -204,6 +204,27 @@ def test_ks256_four_wave_groups():
     assert abs(got - want) <= 0.15 * want, (b, got, want, alt)
 
 
+def test_ks256_saturated_controller_vs_oracle():
+  """The same KS N = 256 model away from the stability boundary: max_step = 2e-4
+  keeps the controller saturated (101 accepted steps to t = 0.02, no rejection:
+  nfev = 2 + 3 x 101 = 305), so no accept / reject decision can amplify rounding
+  noise and the ORACLE check is deterministic: per-sample nfev EQUAL to the
+  reference run (SciPy over the NumPy right-hand side) and trajectories within
+  max(1e-5, 4 x measured floor) over >= 100 steps -- right-hand-side parity for
+  BASELINE configs[3]'s equation under the production integrator, next to the
+  statistical check above."""
+  batch = 8
+  model = make_model('ks', True, num_points=256, resample_factor=2)
+  assert model.kernel_name == 'mfma_f32_r256'
+  y0 = random_phase_ic(model.equation, batch).astype(np.float64)
+  times = np.linspace(0.0, 0.02, 5)
+  nfev, status, bad, worst = _check(model, y0, times, max_step=2e-4, hip_samples=(0, 5))
+  print('ks256 saturated: nfev', nfev, 'worst rel err vs the oracle run {:.1e}'.format(worst))
+  assert not bad, bad
+  assert (nfev == 305).all() and (status == 0).all()
+  assert worst < TOL
+
+
 def test_n128_two_samples_per_group_and_non_power_of_two():
   for num_points in (128, 96):
     model = make_model('kdv', True, num_points=num_points, resample_factor=2)

@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from helpers import oracle, baseline_spec, random_phase_ic, rel_err
+from helpers import (oracle, baseline_spec, baseline_rhs_f64, measured_bound, random_phase_ic,
+                     rel_err)
 from ddd1d_amd import equations, integrate, model as model_lib
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +37,9 @@ def test_weno_rhs_vs_oracle(cls_name, n):
   want = oracle.time_derivative(spec, 0.0, y)
   err = rel_err(got, want)
   print(cls_name, n, 'rel err {:.2e}'.format(err))
-  assert err < (TOL if 'KS' not in cls_name else 1e-4)
+  # 1e-5, or 4 x the float32 oracle's measured distance from the all-float64
+  # evaluation of the same formulas (KS: u_xxx stencils cancel ~1e3-fold)
+  assert err < measured_bound(want, baseline_rhs_f64(spec, y), TOL, cls_name + ' WENO rhs:')
   derivs = model.space_derivatives(y).cpu().numpy()
   np.testing.assert_allclose(derivs[..., 0], np.roll(oracle.weno_reconstruct_left(y), 1, axis=-1),
                              rtol=0, atol=TOL * np.abs(y).max())
@@ -56,14 +59,24 @@ def test_weno_differentiator_vs_reference_trajectories(exact, cls_name, n, seed)
   probe = exact[base + '/probe']
   want_rhs = exact[base + '/rhs_t0.2_probe']
   got_rhs = diff(0.2, probe)
-  assert rel_err(got_rhs, want_rhs) < 2e-5    # float32 kernel vs float64 reference
+  # float32 kernel vs the reference's float64 evaluation: 1e-5, or 4 x the float32
+  # oracle's own distance from that reference value
+  spec = diff.model.spec()
+  frc = ({k: v[0] for k, v in model_lib.forcing_from_equations([eq]).items()}
+         if eq.has_time_dependent_forcing else None)
+  f32_rhs = oracle.time_derivative(spec, 0.2, probe[None], None if frc is None else
+                                   {k: v[None] for k, v in frc.items()})[0]
+  assert rel_err(got_rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, base + ' rhs:')
   ds = integrate.integrate_weno(eq, times=exact[base + '/times'])
   got = np.asarray(ds.data_vars['y'][1] if isinstance(ds.data_vars['y'], tuple)
                    else ds['y'].data)
   want = exact[base + '/y']
   print(base, 'trajectory rel err {:.2e}'.format(rel_err(got, want)),
         'nfev', int(np.asarray(ds.coords['num_evals'])), int(exact[base + '/nfev']))
-  assert rel_err(got, want) < 1e-4
+  # trajectory: the float32 right-hand side under SciPy's adaptive RK23 against the
+  # float64 reference run; floor = the float32 ORACLE under the same SciPy run
+  f32_run, f32_nfev = oracle.odeint_rk23(spec, eq.initial_value(), exact[base + '/times'], frc)
+  assert rel_err(got, want) < measured_bound(f32_run, want, TOL, base + ' trajectory:')
   # mean conservation of the flux form (integrate_test.py:101-104)
   np.testing.assert_allclose(got.mean(axis=1), got[0].mean(), atol=1e-3)
 

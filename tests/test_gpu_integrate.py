@@ -312,8 +312,14 @@ def test_integrate_baseline_vs_reference_golden(golden, cls_name, n, rf, seed, a
   diff = integrate.PolynomialDifferentiator(eq, acc)
   y_probe = eq.initial_value() + 0.1 * np.sin(eq.grid.solution_x)
   rhs = diff(0.1, y_probe)
-  rhs_tol = 2e-3 if 'KS' in cls_name else 2e-5
-  assert rel_err(rhs, golden[key + '/rhs_t0.1_y0']) < rhs_tol
+  # the golden RHS is the reference's float64 evaluation, the kernel's is float32:
+  # bound = max(1e-5, 4 x the float32 oracle's own distance from the golden) -- KS's
+  # 4th-derivative stencils (|c| ~ 6/dx^4) cancel ~1e4-fold on smooth data
+  want_rhs = golden[key + '/rhs_t0.1_y0']
+  f32_rhs = oracle.time_derivative(spec, 0.1, y_probe[None], None if frc is None else
+                                   {k: v[None] for k, v in frc.items()})[0]
+  from helpers import measured_bound
+  assert rel_err(rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, key + ' rhs:')
 
 
 def test_integrate_batch_matches_per_sample_scipy():

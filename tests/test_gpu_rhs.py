@@ -192,13 +192,19 @@ def test_direct_heads_on_mfma(equation, overrides):
   y0 = random_phase_ic(model.equation, 5)
   forcing = batch_forcing(5)
   model.set_forcing(forcing)
-  tol = 1e-4 if overrides.get('polynomial_accuracy_order', 1) == 0 else TOL
+  # polynomial_accuracy_order = 0: unconstrained coefficients do not sum to zero, so
+  # the stencil apply cancels less cleanly; bound = max(1e-5, 4 x the float32 oracle's
+  # measured distance from the all-float64 evaluation) (tol=None), floor printed
+  tol = None if overrides.get('polynomial_accuracy_order', 1) == 0 else TOL
   mfma_err = _check_all_views(model, y0, 0.2, forcing, tol)
   model.set_kernel('mfma256')
   _check_all_views(model, y0, 0.2, forcing, tol)
   model.set_kernel('generic')
   generic_err = _check_all_views(model, y0, 0.2, forcing, tol)
   print(equation, overrides, mfma_err, generic_err)
+  if tol is None:
+    spec = model.spec()
+    tol, _ = _measured_tol(spec, y0, 0.2, forcing, oracle.time_derivative(spec, 0.2, y0, forcing))
   # and over a few steps of the persistent integrator
   model.set_kernel('auto')
   dt = model.equation.time_step
@@ -261,8 +267,36 @@ def test_generic_only_variants(overrides):
   y0 = random_phase_ic(model.equation, 3)
   forcing = batch_forcing(3)
   model.set_forcing(forcing)
-  tol = 1e-4 if overrides.get('polynomial_accuracy_order', 1) == 0 else TOL
-  _check_all_views(model, y0, 0.2, forcing, tol)
+  _check_all_views(model, y0, 0.2, forcing, TOL)
+
+
+@pytest.mark.parametrize('equation,conservative,num_points,resample_factor', [
+    ('burgers', True, 4, 64),    # training_test.py:63: resample_factor = 64 on 256 points
+    ('burgers', False, 6, 32), ('ks', True, 4, 16), ('kdv', False, 6, 16),
+])
+def test_grids_narrower_than_the_stencil(equation, conservative, num_points, resample_factor):
+  """N = 4 / 6 with 6- and 7-point stencils and 5-tap convolutions: the periodic
+  padding wraps more than once around the grid (layers.py:70-75 tiles the input),
+  so stencil points and conv taps alias.  The MFMA path starts at N = 8; these run
+  on the generic kernel: all views vs the oracle, then 20 midpoint steps."""
+  model = make_model(equation, conservative, num_points=num_points,
+                     resample_factor=resample_factor)
+  assert model.stencil_size > num_points
+  assert model.kernel_name == 'generic'
+  batch = 5
+  y0 = random_phase_ic(model.equation, batch)
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  if forcing is not None:
+    model.set_forcing(forcing)
+  _check_all_views(model, y0, 0.1, forcing, None)
+  dt = model.equation.time_step
+  got = model.integrate_fixed(y0, 20, dt=dt, scheme='midpoint', save_every=10).cpu().numpy()
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 20, 10, y0,
+                                forcing=forcing)
+  assert np.isfinite(got).all() and rel_err(got, want) < TOL
+  per_substep = model.integrate_fixed(y0, 20, dt=dt, scheme='midpoint', save_every=10,
+                                      launch_mode='per_substep').cpu().numpy()
+  np.testing.assert_array_equal(got, per_substep)
 
 
 def test_unforced_and_zero_state():
