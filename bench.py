@@ -32,7 +32,9 @@ Timing protocol (every rank):
      lasts >= --min-timed-ms (default 40 ms), otherwise the smallest R that
      fills it.  R is reported as "reps"; "ms_per_step" and "value" are means
      over the R*K timed steps, "roofline.kernel_ms_per_launch" the HIP-event
-     time of the launches divided by their number;
+     time over the R launches (one event pair on the launch stream around all of
+     them) divided by their number; "roofline.frac_wall" the same fraction from
+     the wall clock;
   4. synchronize + barrier; wall = max over ranks.
 
 With N > 1 every rank integrates its own shard of the ensemble (weak scaling,
@@ -56,6 +58,7 @@ cpu_baseline definitions.
 """
 import argparse
 import glob
+import hashlib
 import json
 import math
 import os
@@ -72,11 +75,13 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
+MEASURED_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md: float4 copy, the achievable HBM rate
 TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
 
 
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
-                'rk_substep_external', 'stream_fixed', 'differentiator_b1', 'adaptive_rk23')
+                'rk_substep_external', 'stream_fixed', 'differentiator_b1', 'adaptive_rk23',
+                'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024')
 
 
 def parse_args(argv=None):
@@ -401,24 +406,25 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
   # 3. timed region
   barrier()
   wall0 = time.perf_counter()
-  # one event pair per launch: kernel_ms is launch time only (no collective,
-  # no inter-launch gap), on the stream the kernel is launched on
-  evts = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(reps)]
-  for rep, (e0, e1) in enumerate(evts):
+  # ONE event pair around the R back-to-back launches, on the stream they are
+  # launched on: kernel_ms / launches = the average launch duration including the
+  # dependent-launch gap (a pair per launch put two marker packets between every two
+  # kernels: ~40 us of bubbles per 1.1 ms launch in round 3's line, which is what
+  # made `value` and `roofline.frac` disagree by 3.7 %)
+  start_evt.record()
+  for rep in range(reps):
     slot = rep & 1
     wait_slot(slot)
-    e0.record()
     model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
                           save_every=args.steps, launch_mode=args.launch_mode,
                           state_dtype=args.state_dtype, out=finals[slot])
-    e1.record()
     if world > 1:
       gather_final(slot)
+  stop_evt.record()
   barrier()
   wall1 = time.perf_counter()
   wall = wall1 - wall0
-  kernel_ms = sum(e0.elapsed_time(e1) for e0, e1 in evts)
+  kernel_ms = start_evt.elapsed_time(stop_evt)
   clocks = sampler.stop(wall0, wall1) if sampler is not None else None
 
   per_rank = None
@@ -441,7 +447,12 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
     per_rank = {'wall_ms': [float(v) for v in table[:, 0]],
                 'kernel_ms': [float(v) for v in table[:, 1]],
                 'gather_ms_isolated': [float(v) for v in table[:, 2]],
-                'gather_bytes_per_rank': int(finals[0][0].numel() * finals[0].element_size())}
+                'gather_bytes_per_rank': int(finals[0][0].numel() * finals[0].element_size()),
+                # the gathered ensemble after `steps` steps from y0 (rank slabs in rank
+                # order): equals the single-process run of the same global sample ids
+                'gathered_sha1': hashlib.sha1(
+                    gathers[0].cpu().numpy().tobytes()).hexdigest(),
+                'gathered_shape': list(gathers[0].shape)}
     wall, kernel_ms = float(table[:, 0].max()) * 1e-3, float(table[:, 1].max())
   finite = bool(torch.isfinite(finals[0]).all())
   if not finite:
@@ -491,6 +502,20 @@ def summarize(args, eq, model, m, world, n, batch, stages):
       'fp32_tflops': achieved_tflops,
       'fp32_frac': achieved_tflops / PEAK_FP32_TFLOPS,
   }
+  # the same fraction from the WALL clock of the timed region (what `value` is made
+  # of): below `frac` by the host gaps between the launches of a job list
+  wall_per_launch = m['wall'] / launches
+  roofline['frac_wall'] = ((flops_per_launch / wall_per_launch / 1e12 / PEAK_FP32_TFLOPS)
+                           if compute_bound else
+                           (bytes_per_launch / wall_per_launch / 1e9 / PEAK_HBM_GBPS))
+  if not compute_bound and args.launch_mode == 'per_substep':
+    # `frac` prices the bytes the launches actually move (midpoint: 8 B/point in stage
+    # 1, 12 in stage 2, where y_n is read again: 10 on average, counter-verified);
+    # SURVEY section 8(d)'s algorithmic figure is 8 B per grid-point-substep
+    algorithmic = 8.0 * batch * n / launch_s / 1e9
+    roofline['frac_algorithmic'] = algorithmic / PEAK_HBM_GBPS
+    roofline['algorithmic_gbps'] = algorithmic
+    roofline['frac_of_copy_rate'] = achieved_gbps / MEASURED_COPY_GBPS
   return {
       'value': total_points / m['wall'],
       'ms_per_step': m['wall'] * 1e3 / steps_timed,
@@ -525,7 +550,11 @@ def _fixed_step_config(args, lib, world, name, note, batch, unique=None, **overr
       'roofline_unit': r['unit'], 'frac': r['frac'],
       'kernel_ms_per_launch': r['kernel_ms_per_launch'], 'launches': r['launches'],
       'traffic': r['traffic'], 'traffic_source': r['traffic_source'], 'finite': m['finite'],
+      'frac_wall': r['frac_wall'],
   }
+  for key in ('frac_algorithmic', 'algorithmic_gbps', 'frac_of_copy_rate'):
+    if key in r:
+      out[key] = r[key]
   model.close()
   return name, out
 
@@ -702,16 +731,17 @@ def _differentiator_config(args):
   return 'differentiator_b1', result
 
 
-def _adaptive_config(args):
+def _adaptive_config(args, name='adaptive_rk23', batch=4096, t_end=1.0, unique=None):
   """`ddd_integrate_adaptive_f64`: the reference's production integrator
   (solve_ivp RK23, max_step 0.01, integrate.py:143-169) for the whole batch in
-  one launch, one controller per sample; float64 state, float32 right-hand side."""
+  one launch, one controller per sample; float64 state, float32 right-hand side.
+  Burgers sits at max_step (saturated controller), KdV and KS are stability-limited
+  (continuous rejections; KS N=256 is one sample per four-wave group)."""
   import torch
   a = _variant(args)
-  batch = 4096
-  eq, model, _, y0 = build_workload(a, 0, batch)
+  eq, model, _, y0 = build_workload(a, 0, batch, unique=unique)
   n = eq.grid.solution_num_points
-  times = np.linspace(0.0, 1.0, 11)
+  times = np.linspace(0.0, t_end, 11)
   y0d = torch.from_numpy(y0.astype(np.float64)).cuda()
   model.integrate_adaptive(y0d, times)
   torch.cuda.synchronize()
@@ -729,23 +759,33 @@ def _adaptive_config(args):
   nfev = nfev.cpu().numpy().astype(np.int64)
   evals = float(nfev.sum()) * n              # grid-point-evaluations per launch
   steps = float(((nfev - 2) // 3).sum()) * n   # grid-point-steps (attempted RK23 steps)
+  # samples of one workgroup share evaluations: a group runs as long as its slowest
+  # sample, so the matrix work ISSUED is the per-group maximum (useful = the sum)
+  spg = max(1, (64 if n <= 64 and 64 % n == 0 else 256) // n)
+  pad = (-len(nfev)) % spg
+  issued = float(np.pad(nfev, (0, pad)).reshape(-1, spg).max(axis=1).sum()) * spg * n
   tflops = 2.0 * model.fma_per_point * evals * launches / (kernel_ms * 1e-3) / 1e12
   result = {
-      'workload': 'Burgers N={} conv-net stencils, batch {}, solve_ivp-RK23 semantics per '
-                  'sample (rtol 1e-3, atol 1e-6, max_step 0.01), t in [0, 1], 11 output '
-                  'times, {} launches'.format(n, batch, launches),
+      'workload': '{} N={} conv-net stencils, batch {}{}, solve_ivp-RK23 semantics per '
+                  'sample (rtol 1e-3, atol 1e-6, max_step 0.01), t in [0, {:g}], 11 output '
+                  'times, {} launches'.format(
+                      a.equation, n, batch,
+                      '' if unique is None else ' TILED from {} distinct samples'.format(unique),
+                      t_end, launches),
       'value': evals * launches / (kernel_ms * 1e-3), 'unit': 'grid-point-evaluations/s',
       'grid_point_steps_per_s': steps * launches / (kernel_ms * 1e-3),
       'nfev_min': int(nfev.min()), 'nfev_max': int(nfev.max()),
+      'nfev_mean': float(nfev.mean()),
       'samples_finished': int((status.cpu().numpy() == 0).sum()),
       'kernel_ms_per_launch': kernel_ms / launches, 'timed_wall_ms': wall * 1e3,
       'kernel': model.kernel_name, 'state_dtype': 'float64',
       'bound': 'mfma', 'achieved': tflops, 'peak': PEAK_FP32_TFLOPS,
       'roofline_unit': 'TFLOP/s', 'frac': tflops / PEAK_FP32_TFLOPS,
+      'frac_issued': tflops / PEAK_FP32_TFLOPS * issued / max(evals, 1.0),
       'finite': bool(torch.isfinite(y).all()),
   }
   model.close()
-  return 'adaptive_rk23', result
+  return name, result
 
 
 def extra_configs(args, lib, world):
@@ -768,8 +808,9 @@ def extra_configs(args, lib, world):
     elif name == 'ks_n256_b8192':
       key, val = _fixed_step_config(
           args, lib, world, name, 'BASELINE.json configs[3]: KS N=256, conv-net stencils, '
-          'batch 8192, midpoint at the equation time step (400-step jobs; the 10k-step '
-          'horizon is one longer launch of the same kernel)', 8192, unique=1024,
+          'batch 8192 TILED from 1024 distinct samples, midpoint at the equation time step '
+          '(400-step jobs; the 10k-step horizon is one longer launch of the same kernel, '
+          'tests/test_gpu_full_size.py runs it once)', 8192, unique=1024,
           **dict(base, equation='ks', num_points=256, steps=400))
     elif name == 'burgers_per_substep':
       key, val = _fixed_step_config(
@@ -789,14 +830,20 @@ def extra_configs(args, lib, world):
     elif name == 'stream_fixed':
       key, val = _fixed_step_config(
           args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '
-          'KdV N=64 batch 262144, one launch per substep: the HBM-bound kernel of the path',
-          262144, unique=4096,
+          'KdV N=64 batch 262144 TILED from 4096 distinct samples, one launch per substep: '
+          'the HBM-bound kernel of the path', 262144, unique=4096,
           **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_substep',
                  steps=200))
     elif name == 'differentiator_b1':
       key, val = _differentiator_config(_variant(args, **base))
-    else:
+    elif name == 'adaptive_rk23':
       key, val = _adaptive_config(_variant(args, **base))
+    elif name == 'adaptive_kdv_n64_b4096':
+      key, val = _adaptive_config(_variant(args, **dict(base, equation='kdv')), name, 4096,
+                                  t_end=0.05, unique=1024)
+    else:
+      key, val = _adaptive_config(_variant(args, **dict(base, equation='ks', num_points=256)),
+                                  name, 1024, t_end=0.02, unique=256)
     out[key] = val
   return out
 
@@ -808,12 +855,29 @@ def relaunch_under_torchrun(args):
   with socket.socket() as s:
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
+  import tempfile
+  log_dir = tempfile.mkdtemp(prefix='bench_ranks_')
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
          '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
-         '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+         '--master-port', str(port), '--log-dir', log_dir, '--redirects', '2',
+         os.path.abspath(__file__)] + sys.argv[1:]
   env = dict(os.environ)
   env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-  return subprocess.call(cmd, env=env)
+  rc = subprocess.call(cmd, env=env)
+  # every rank's stderr went to its own log file (stdout stays the one JSON line):
+  # replayed here rank by rank, so that a dead rank never passes silently
+  for path in sorted(glob.glob(os.path.join(log_dir, '**', 'stderr.log'), recursive=True)):
+    try:
+      with open(path) as f:
+        tail = f.read()[-3000:]
+    except OSError:
+      continue
+    if tail.strip():
+      sys.stderr.write('---- {} ----\n{}\n'.format(os.path.relpath(path, log_dir), tail))
+  if rc != 0:
+    sys.stderr.write('bench.py: torch.distributed.run exited with {} for --gpus {} '
+                     '(visible devices: see the rank logs above)\n'.format(rc, args.gpus))
+  return rc
 
 
 def main():
@@ -863,7 +927,7 @@ def main():
         'batch_per_gpu': b2, 'value': s2['value'], 'unit': 'grid-point-steps/s',
         'ms_per_step': s2['ms_per_step'], 'reps': m2['reps'],
         'fp32_tflops': s2['roofline']['fp32_tflops'],
-        'frac': s2['roofline']['frac'],
+        'frac': s2['roofline']['frac'], 'frac_wall': s2['roofline']['frac_wall'],
         'kernel_ms_per_launch': s2['roofline']['kernel_ms_per_launch'],
         'kernel': model2.kernel_name, 'finite': m2['finite'],
     }
@@ -909,6 +973,7 @@ def main():
             'fma_per_point_eval': model.fma_per_point,
             'parallelism': 'ensemble-shard x{}'.format(world),
             'backend': args.backend if world > 1 else None,
+            'visible_devices': torch.cuda.device_count(),
             'finite': m['finite'],
             'debug_options': args.debug_option, 'hparams': json.loads(args.hparams or '{}'),
             'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,

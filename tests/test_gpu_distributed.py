@@ -105,6 +105,50 @@ def test_bench_two_ranks_on_this_box():
   assert result['configs'] is None
 
 
+def test_bench_eight_ranks_on_this_box():
+  """The command shape of the first 8-GPU run -- `bench.py --gpus 8`, self-launched
+  under torch.distributed.run -- with eight ranks sharing cuda:0 over gloo: the
+  8-rank rendezvous, the agreed repetition count, per-rank tables of length 8 and
+  the gathered ensemble, which must equal the single-process run of the same 512
+  global sample ids bit for bit."""
+  import hashlib
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8',
+                        '--backend', 'gloo', '--batch', '64', '--steps', '5', '--warmup', '2',
+                        '--preheat-ms', '10', '--min-timed-ms', '5', '--configs', 'none',
+                        '--cpu-seconds', '0'], env=env, capture_output=True, text=True,
+                       timeout=1200)
+  assert out.returncode == 0, out.stderr[-3000:]
+  line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+  result = json.loads(line)
+  assert result['n_gpus'] == 8 and result['config']['global_batch'] == 512
+  assert result['config']['visible_devices'] == torch.cuda.device_count()
+  assert result['config']['finite'] and result['value'] > 0 and result['scaling'] == 'weak'
+  per_rank = result['per_rank']
+  for key in ('wall_ms', 'kernel_ms', 'gather_ms_isolated'):
+    assert len(per_rank[key]) == 8 and all(v > 0 for v in per_rank[key]), key
+  assert per_rank['gathered_shape'] == [512, 64]
+  # the single-process run of global sample ids 0 .. 511 (rank r owns [64 r, 64 r + 64))
+  import bench
+  args = bench.parse_args(['--batch', '512', '--steps', '5'])
+  eq, model, _, y0 = bench.build_workload(args, 0, 512)
+  want = model.integrate_fixed(y0, 5, dt=eq.time_step, scheme='midpoint', save_every=5)[0]
+  assert per_rank['gathered_sha1'] == hashlib.sha1(want.cpu().numpy().tobytes()).hexdigest()
+
+
+def test_bench_reports_a_dead_rank(tmp_path):
+  """A rank that dies must fail the whole command, with that rank's own stderr."""
+  env = {k: v for k, v in os.environ.items()
+         if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+  out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+                        '--backend', 'gloo', '--batch', '64', '--steps', '5',
+                        '--configs', 'none', '--cpu-seconds', '0', '--equation', 'nonsense'],
+                       env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode != 0
+  assert 'stderr.log' in out.stderr and 'torch.distributed.run exited with' in out.stderr
+
+
 def test_bench_rccl_path_with_one_rank():
   """The RCCL calls bench.py makes with N > 1 -- init with device_id, broadcast of
   the repetition count, async all_gather_into_tensor of a [batch, x] slab into

@@ -332,3 +332,20 @@ def test_spectral_adaptive_large_grid_and_failure(monkeypatch):
       want, want_nfev = integrate.odeint(y0[b], diff, times)
       assert int(nfev[b]) == want_nfev and int(status[b]) == 0, (n, b, int(nfev[b]), want_nfev)
       assert rel_err(y[:, b].cpu().numpy(), want) < 1e-9
+
+
+def test_spectral_adaptive_refuses_the_forced_family():
+  """The spectral adaptive kernel has no forcing term: a Burgers spectral model
+  (finalize_time_derivative adds forcing(t), equations.py:276-277) is refused by
+  ddd_integrate_adaptive_f64 instead of silently integrating the unforced
+  equation; KdV / KS (no forcing) are accepted."""
+  from ddd1d_amd import _lib
+  eq = equations.BurgersEquation(64, random_seed=1)
+  model = model_lib.SpectralModel(eq, convention='fftpack')
+  y0 = eq.initial_value()[None].astype(np.float64)
+  with pytest.raises(_lib.DDDError, match='no forcing term'):
+    model.integrate_adaptive(y0, np.linspace(0.0, 0.01, 3))
+  kdv = equations.KdVEquation(64, random_seed=1)
+  y, nfev, status = model_lib.SpectralModel(kdv, convention='fftpack').integrate_adaptive(
+      kdv.initial_value()[None].astype(np.float64), np.linspace(0.0, 1e-4, 3))
+  assert int(status[0]) == 0 and np.isfinite(y.cpu().numpy()).all()
