@@ -130,6 +130,10 @@ def parse_args(argv=None):
                   help='library A/B switch (ddd_debug_set_option of libddd1d_probe.so, '
                        '__graft_entry__.build_probe), e.g. no_spec=1; logged to stderr, never '
                        'set in a headline run')
+  ap.add_argument('--library', default=None, metavar='NAME',
+                  help='A/B build of the library to load instead of the product one '
+                       '(csrc/libddd1d_<NAME>.so, __graft_entry__.build_hip(variant=NAME)); named '
+                       'in config.library, never a headline run')
   ap.add_argument('--cpu-seconds', type=float, default=12.0,
                   help='budget for the CPU baseline sample (0 disables)')
   args = ap.parse_args(argv)
@@ -901,7 +905,10 @@ def main():
       dist.init_process_group('gloo')
 
   import ddd1d_amd
-  if args.debug_option:
+  if args.library:
+    lib = ddd1d_amd._lib.load_library(os.path.join(
+        os.path.dirname(ddd1d_amd._lib.LIBRARY_PATH), 'libddd1d_{}.so'.format(args.library)))
+  elif args.debug_option:
     # A/B switches live in the probe flavour of the library only (never a headline run)
     lib = ddd1d_amd._lib.load_probe_library()
   else:
@@ -975,7 +982,7 @@ def main():
             'backend': args.backend if world > 1 else None,
             'visible_devices': torch.cuda.device_count(),
             'finite': m['finite'],
-            'debug_options': args.debug_option, 'hparams': json.loads(args.hparams or '{}'),
+            'debug_options': args.debug_option, 'library': args.library, 'hparams': json.loads(args.hparams or '{}'),
             'preheat_ms': m['preheat_ms'], 'min_timed_ms': args.min_timed_ms,
             'timed_wall_ms': m['wall'] * 1e3,
         },
