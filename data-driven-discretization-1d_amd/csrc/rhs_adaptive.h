@@ -42,6 +42,19 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
     // groups of N lanes; a + b == b + a, so every lane ends with the same bits
     for (int m = 1; m < p.N; m <<= 1) v += __shfl_xor(v, m, 64);
     return v;
+  } else if ((p.N & 63) == 0) {
+    // a sample is N / 64 whole wavefronts (KS N = 256: all four): xor butterfly
+    // inside each wavefront, then the sample's wave totals in a fixed order --
+    // 6 shuffles + <= 4 adds instead of a serial N-term loop per lane
+    // (rk23.h: block_sum256 is the N = 256 case).  (wave-uniform branch)
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    if (ln.lane == 0) red[ln.wave] = v;
+    __syncthreads();
+    const int w0 = ln.base >> 6, nw = p.N >> 6;
+    double s = red[w0];
+    for (int i = 1; i < nw; ++i) s += red[w0 + i];
+    __syncthreads();
+    return s;
   } else {
     red[ln.row] = v;
     __syncthreads();
@@ -79,32 +92,48 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
     return sqrt(sample_sum<kRows, kWR>(p, ln, q * q, red)) / sqrt_n;
   };
 
-  rk23::Control c;   // this lane's copy of its SAMPLE's controller (identical on its lanes)
-  c.init(t0, ln.valid != 0);
+  // The step-size controllers live in LDS, one per sample of the group: their 7
+  // doubles + 4 ints are identical on all lanes of a sample and are touched once
+  // per evaluation, so as per-lane registers they were spilled to scratch (~90
+  // scratch operations per attempt at 256 VGPRs).  A lane reads its sample's
+  // controller (broadcast reads) where the evaluation's input is formed and again
+  // after the evaluation; the lane of grid point 0 writes it back.  Per lane and
+  // across the evaluation only the state and the stage derivatives stay live.
+  __shared__ rk23::Control ctl[kRows / 8];
+  __shared__ long long attempts_of[kRows / 8];
+  const int slot = ln.sl;
+  const bool keeper = row_live && ln.pos == 0 && ln.owner;
+  {
+    rk23::Control c0;
+    c0.init(t0, ln.valid != 0);
+    if (keeper) { ctl[slot] = c0; attempts_of[slot] = 0; }
+  }
+  group_barrier<kRows, kWR>();
   double y = ln.valid ? a.y0[ln.gidx] : 0.0;
   double y_new = y;
   float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f;
-  // select_initial_step's h0 and d1 live only until the first attempt starts:
-  // they ride in c.h and c.t_new (set by begin_attempt after their last use),
-  // which keeps the loop-carried state inside the register budget
-  double& h0 = c.h;
-  double& d1 = c.t_new;
-  long long attempts = 0;
 
   // phase 0: f(t0, y0); 1: the probe of select_initial_step; 2..4: stages 2, 3
   // and the FSAL stage of one attempt.  Uniform over the workgroup.
+  // select_initial_step's h0 and d1 live only until the first attempt starts:
+  // they ride in Control::h and Control::t_new (set by begin_attempt after their
+  // last use).
   int phase = 0;
   bool sums_ready = false;   // res.fk_next already holds the forcing sums of this evaluation
   for (;;) {
     double tt, yy, tt_next;
-    if (phase == 0) { tt = c.t; yy = y; tt_next = tt; }
-    else if (phase == 1) { tt = c.t + h0; yy = y + h0 * (double)k0; tt_next = tt; }
-    else if (phase == 2) {
-      tt = c.t + 0.5 * c.h; yy = rk23::stage2_input(y, k0, c.h); tt_next = c.t + 0.75 * c.h;
-    } else if (phase == 3) {
-      tt = c.t + 0.75 * c.h; yy = rk23::stage3_input(y, k0, k1, c.h); tt_next = c.t + c.h;
-    } else { tt = c.t + c.h; yy = y_new; tt_next = tt; }
-    if (c.status != rk23::RUNNING) { tt = c.t; yy = y; tt_next = c.t; }   // idle samples stay finite
+    {
+      const double ct = ctl[slot].t, ch = ctl[slot].h;   // (phase 1: h = h0)
+      const int cstatus = ctl[slot].status;
+      if (phase == 0) { tt = ct; yy = y; tt_next = tt; }
+      else if (phase == 1) { tt = ct + ch; yy = y + ch * (double)k0; tt_next = tt; }
+      else if (phase == 2) {
+        tt = ct + 0.5 * ch; yy = rk23::stage2_input(y, k0, ch); tt_next = ct + 0.75 * ch;
+      } else if (phase == 3) {
+        tt = ct + 0.75 * ch; yy = rk23::stage3_input(y, k0, k1, ch); tt_next = ct + ch;
+      } else { tt = ct + ch; yy = y_new; tt_next = tt; }
+      if (cstatus != rk23::RUNNING) { tt = ct; yy = y; tt_next = ct; }   // idle samples stay finite
+    }
 
     // Harmonic forcing sums at THIS sample's time.  Inside an attempt the next
     // stage's time is known, so stages 3 and 4 get their sums from the look-ahead
@@ -121,7 +150,12 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false>(
         p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
     sums_ready = ahead;
+    // (eval_rhs's barriers are compiler barriers too: this is a fresh read)
+    rk23::Control c = ctl[slot];
     if (c.status == rk23::RUNNING) ++c.nfev;
+    long long attempts = -1;   // phase 4: the sample's attempt count after this one
+    double& h0 = c.h;
+    double& d1 = c.t_new;
 
     if (phase == 0) {
       k0 = f;
@@ -165,20 +199,28 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
         k0 = k3;
         c.advance(t_bound, max_step);
       }
-      ++attempts;
+      attempts = attempts_of[slot] + 1;
       if (c.status == rk23::RUNNING && attempts >= a.max_attempts) c.status = rk23::ATTEMPT_LIMIT;
       c.begin_attempt(t_bound);
       phase = 2;
     }
-    // the workgroup is done when none of its samples is running
+    // every lane of the sample has read the controller (above); the keeper publishes
+    // the new one.  The vote below is the barrier that orders it before the next read.
     const int running = c.status == rk23::RUNNING;
+    if (kRows != kWR) __syncthreads();   // four-wave groups: all lanes' reads before the write
+    if (keeper) {
+      ctl[slot] = c;
+      if (attempts >= 0) attempts_of[slot] = attempts;
+    }
     if (kRows == kWR) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!__any(running)) break;
     } else {
       if (!__syncthreads_or(running)) break;
     }
   }
 
+  const rk23::Control c = ctl[slot];
   if (ln.active) {
     if (c.status != rk23::FINISHED) {
       const double nan = __longlong_as_double(0x7ff8000000000000ll);
