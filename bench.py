@@ -844,7 +844,7 @@ def extra_configs(args, lib, world):
       key, val = _adaptive_config(_variant(args, **base))
     elif name == 'adaptive_kdv_n64_b4096':
       key, val = _adaptive_config(_variant(args, **dict(base, equation='kdv')), name, 4096,
-                                  t_end=0.05, unique=1024)
+                                  t_end=0.2, unique=1024)
     else:
       key, val = _adaptive_config(_variant(args, **dict(base, equation='ks', num_points=256)),
                                   name, 1024, t_end=0.02, unique=256)

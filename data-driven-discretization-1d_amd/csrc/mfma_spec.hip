@@ -68,7 +68,7 @@ void adaptive_spec<DDD_EQ>(int rows, const DevParams& p, const AdaptiveArgs& a, 
     hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ>), dim3(blocks), dim3(64), 0,
                        stream, p, a);
   else
-    hipLaunchKernelGGL((mfma::adaptive_kernel<256, 64, true, DDD_EQ>), dim3(blocks), dim3(256),
+    hipLaunchKernelGGL((mfma::adaptive_kernel<256, 64, false, DDD_EQ>), dim3(blocks), dim3(256),
                        0, stream, p, a);
 }
 

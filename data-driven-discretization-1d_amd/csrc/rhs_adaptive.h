@@ -42,7 +42,11 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
     // groups of N lanes; a + b == b + a, so every lane ends with the same bits
     for (int m = 1; m < p.N; m <<= 1) v += __shfl_xor(v, m, 64);
     return v;
-  } else if ((p.N & 63) == 0) {
+  }
+  // four-wave groups: `red` aliases Shared::un + Shared::flux (free between two
+  // evaluations) -- slower wavefronts may still be reading the flux exchange
+  __syncthreads();
+  if ((p.N & 63) == 0) {
     // a sample is N / 64 whole wavefronts (KS N = 256: all four): xor butterfly
     // inside each wavefront, then the sample's wave totals in a fixed order --
     // 6 shuffles + <= 4 adds instead of a serial N-term loop per lane
@@ -66,13 +70,54 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
   }
 }
 
+// The per-sample controllers as they live in LDS (40 bytes: the 256-row kernels
+// have 1.6 KB of LDS to spare next to Shared<256> if two workgroups are to share a CU).
+struct PackedControl {
+  double t, t_new, h, h_abs;
+  int nfev;
+  int bits;   // (status + 2) | rejected << 2 | ti << 3
+  __device__ __forceinline__ void store(const rk23::Control& c) {
+    t = c.t; t_new = c.t_new; h = c.h; h_abs = c.h_abs; nfev = c.nfev;
+    bits = (c.status + 2) | ((c.rejected ? 1 : 0) << 2) | (c.ti << 3);
+  }
+  __device__ __forceinline__ rk23::Control load() const {
+    rk23::Control c;
+    c.t = t; c.t_new = t_new; c.h = h; c.h_abs = h_abs; c.nfev = nfev;
+    const int b = bits;
+    c.status = (b & 3) - 2; c.rejected = ((b >> 2) & 1) != 0; c.ti = b >> 3;
+    return c;
+  }
+  __device__ __forceinline__ int status() const { return (bits & 3) - 2; }
+};
+static_assert(rk23::ATTEMPT_LIMIT == -2 && rk23::RUNNING == 1, "status + 2 fits two bits");
+
+template <int kRows>
+struct AdaptiveShared {
+  PackedControl ctl[kRows / 8];      // one per sample of the group (N >= 8)
+  int attempts_of[kRows / 8];        // saturating (2^31 attempts of one sample = hours)
+  int vote[2];
+};
+// (budgets: 8 x 64-row workgroups per CU leave 376 bytes next to Shared<64>, 2 x 256-row
+// workgroups 1600 next to Shared<256>)
+static_assert(sizeof(Shared<64>) + sizeof(AdaptiveShared<64>) <= 20 * 1024, "8 groups per CU");
+
+#ifndef DDD_ADAPTIVE_LEAN
+#define DDD_ADAPTIVE_LEAN 0   // A/B (profiles/r4_ablation.txt): bit 0 = 64-row groups lean, bit 1 = 256-row
+#endif
+template <int kRows>
+constexpr bool adaptive_lean() { return ((kRows == 64 ? 1 : 2) & DDD_ADAPTIVE_LEAN) != 0; }
+
 template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams p,
                                                                        AdaptiveArgs a) {
   __shared__ Shared<kRows, kWR, kWide> sm;
-  __shared__ double red[kRows == kWR ? 2 : kRows];
-  // evaluation time of each sample of the group (N >= 8), and of its NEXT evaluation
-  __shared__ float tev[kRows / 8], tev_next[kRows / 8];
+  __shared__ AdaptiveShared<kRows> as;
+  static_assert(kRows == kWR || kWide ||
+                    sizeof(Shared<kRows, kWR, kWide>) + sizeof(AdaptiveShared<kRows>) <= 80 * 1024,
+                "two 256-row workgroups per CU");
+  // reduction scratch of sample_sum: one-wave groups shuffle; four-wave groups use
+  // Shared::un + Shared::flux (2 x kRows floats = kRows doubles), free between evaluations
+  double* red = kRows == kWR ? nullptr : reinterpret_cast<double*>(sm.un);
   const int tid = (int)threadIdx.x;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, (int)blockIdx.x);
   Resident res;
@@ -99,14 +144,16 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
   // controller (broadcast reads) where the evaluation's input is formed and again
   // after the evaluation; the lane of grid point 0 writes it back.  Per lane and
   // across the evaluation only the state and the stage derivatives stay live.
-  __shared__ rk23::Control ctl[kRows / 8];
-  __shared__ long long attempts_of[kRows / 8];
+  PackedControl* ctl = as.ctl;
+  int* attempts_of = as.attempts_of;
+  int* vote = as.vote;
+  if (tid == 0) { vote[0] = 0; vote[1] = 0; }
   const int slot = ln.sl;
   const bool keeper = row_live && ln.pos == 0 && ln.owner;
   {
     rk23::Control c0;
     c0.init(t0, ln.valid != 0);
-    if (keeper) { ctl[slot] = c0; attempts_of[slot] = 0; }
+    if (keeper) { ctl[slot].store(c0); attempts_of[slot] = 0; }
   }
   group_barrier<kRows, kWR>();
   double y = ln.valid ? a.y0[ln.gidx] : 0.0;
@@ -119,12 +166,13 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
   // they ride in Control::h and Control::t_new (set by begin_attempt after their
   // last use).
   int phase = 0;
+  int round = 0;
   bool sums_ready = false;   // res.fk_next already holds the forcing sums of this evaluation
   for (;;) {
     double tt, yy, tt_next;
     {
       const double ct = ctl[slot].t, ch = ctl[slot].h;   // (phase 1: h = h0)
-      const int cstatus = ctl[slot].status;
+      const int cstatus = ctl[slot].status();
       if (phase == 0) { tt = ct; yy = y; tt_next = tt; }
       else if (phase == 1) { tt = ct + ch; yy = y + ch * (double)k0; tt_next = tt; }
       else if (phase == 2) {
@@ -142,25 +190,38 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
     const bool ahead = fast_frc && (phase == 2 || phase == 3);
     float tn_lane = (float)tt;
     if (fast_frc) {
-      if (row_live && ln.pos == 0) { tev[ln.sl] = (float)tt; tev_next[ln.sl] = (float)tt_next; }
-      __syncthreads();
-      if (!sums_ready) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, tev[frc_sl], tid);
-      tn_lane = tev_next[frc_sl];
+      // the lane's (sample, mode) pair of forcing phase 1 belongs to sample frc_sl of
+      // the group, not to the lane's own: that sample's evaluation times, formed from
+      // ITS controller exactly as above
+      const double ft = ctl[frc_sl].t, fh = ctl[frc_sl].h;
+      const bool frun = ctl[frc_sl].status() == rk23::RUNNING;
+      double ft_now = ft, ft_next = ft;
+      if (frun) {
+        if (phase == 1) { ft_now = ft + fh; ft_next = ft_now; }
+        else if (phase == 2) { ft_now = ft + 0.5 * fh; ft_next = ft + 0.75 * fh; }
+        else if (phase == 3) { ft_now = ft + 0.75 * fh; ft_next = ft + fh; }
+        else if (phase == 4) { ft_now = ft + fh; ft_next = ft_now; }
+      }
+      if (!sums_ready) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)ft_now, tid);
+      tn_lane = (float)ft_next;
     }
-    const float f = eval_rhs<kRows, kWR, kHoist, kEq, false>(
+    const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>()>(
         p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
     sums_ready = ahead;
     // (eval_rhs's barriers are compiler barriers too: this is a fresh read)
-    rk23::Control c = ctl[slot];
+    rk23::Control c = ctl[slot].load();
     if (c.status == rk23::RUNNING) ++c.nfev;
-    long long attempts = -1;   // phase 4: the sample's attempt count after this one
+    int attempts = -1;   // phase 4: the sample's attempt count after this one
     double& h0 = c.h;
     double& d1 = c.t_new;
 
     if (phase == 0) {
       k0 = f;
       if (a.n_times == 1) {   // t0 == t_bound: nothing to integrate
-        if (c.status == rk23::RUNNING) { a.y_out[ln.gidx] = y; c.ti = 1; c.status = rk23::FINISHED; }
+        if (c.status == rk23::RUNNING) {
+          if (ln.active) a.y_out[ln.gidx] = y;
+          c.ti = 1; c.status = rk23::FINISHED;
+        }
       } else {
         const double scale = atol + fabs(y) * rtol;
         const double d0 = rms(y / scale);
@@ -191,16 +252,20 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
         while (c.ti < a.n_times) {
           const double te = a.times[c.ti];
           if (!(te <= c.t_new)) break;
-          a.y_out[(size_t)c.ti * row_stride + ln.gidx] =
-              rk23::dense_output(y, k0, k1, k2, k3, (te - c.t) / c.h, c.h);
+          // (spare rows of a 256-row group follow sample 0's controller: no stores)
+          if (ln.active)
+            a.y_out[(size_t)c.ti * row_stride + ln.gidx] =
+                rk23::dense_output(y, k0, k1, k2, k3, (te - c.t) / c.h, c.h);
           ++c.ti;
         }
         y = y_new;
         k0 = k3;
         c.advance(t_bound, max_step);
       }
-      attempts = attempts_of[slot] + 1;
-      if (c.status == rk23::RUNNING && attempts >= a.max_attempts) c.status = rk23::ATTEMPT_LIMIT;
+      attempts = attempts_of[slot];
+      if (attempts < 0x7fffffff) ++attempts;
+      if (c.status == rk23::RUNNING && (long long)attempts >= a.max_attempts)
+        c.status = rk23::ATTEMPT_LIMIT;
       c.begin_attempt(t_bound);
       phase = 2;
     }
@@ -209,18 +274,27 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
     const int running = c.status == rk23::RUNNING;
     if (kRows != kWR) __syncthreads();   // four-wave groups: all lanes' reads before the write
     if (keeper) {
-      ctl[slot] = c;
+      ctl[slot].store(c);
       if (attempts >= 0) attempts_of[slot] = attempts;
     }
     if (kRows == kWR) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (!__any(running)) break;
     } else {
-      if (!__syncthreads_or(running)) break;
+      // workgroup vote through two alternating LDS flags.  (Not __syncthreads_or:
+      // its device-library reduction makes the compiler assume the kernel may need
+      // AGPRs, the MFMAs then take their AGPR form and 256 VGPRs + 72 AGPRs leave
+      // ONE wavefront per SIMD instead of two: KS N = 256 ran at 49 % of peak.)
+      if (running) vote[round & 1] = 1;
+      if (tid == 0) vote[(round + 1) & 1] = 0;   // next round's flag; its readers are long gone
+      __syncthreads();
+      const int go = vote[round & 1];
+      ++round;
+      if (!go) break;
     }
   }
 
-  const rk23::Control c = ctl[slot];
+  const rk23::Control c = ctl[slot].load();
   if (ln.active) {
     if (c.status != rk23::FINISHED) {
       const double nan = __longlong_as_double(0x7ff8000000000000ll);

@@ -654,7 +654,10 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 // evaluation after this one) at the layer boundaries.
 // ablate / trace: profiling hooks of libddd1d_probe.so (-DDDD_PROBES); every
 // product call site passes the defaults, so they fold away.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide>
+// kLean (adaptive integrators): the output layer's weights and the cos / sin table
+// are NOT kept resident (fetched from L2 / the LDS row padding per evaluation like
+// the run-time kernels do): 31-43 VGPRs the controller state needs.
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide, bool kLean = false>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR, kWide>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
@@ -699,7 +702,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // the per-equation ones also the output layer's weights and the grid point's
   // cos / sin table (kKeepRows)
   constexpr bool kKeepOffsets = kWR == 64 && kHoist;
-  constexpr bool kKeepRows = kKeepOffsets && kEq >= 0;
+  constexpr bool kKeepRows = kKeepOffsets && kEq >= 0 && !kLean;
   constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
   const int tid = opaque(group_tid<kRows, kWR>());
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
@@ -919,7 +922,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // the epilogue, consumed by its last statement
   float4 trig4[kTrigMax / 4];
   if (forced && fast_forcing) {
-    if (kKeepOffsets) {
+    if (kKeepOffsets && !kLean) {
       // resident for the launch: lane == grid point never changes
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = res.trig[i];
@@ -1078,7 +1081,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
-        if (i == 2 && trig_lds && !kKeepOffsets) break;   // entries 8..11 are zero padding
+        if (i == 2 && trig_lds && !(kKeepOffsets && !kLean)) break;   // entries 8..11 are zero padding
         const float4 f = fk4[i];
         total = fmaf(f.x, trig4[i].x, total);
         total = fmaf(f.y, trig4[i].y, total);
