@@ -52,17 +52,50 @@ __host__ __device__ constexpr int tab_rows(bool wide) { return 4 + flavour_chann
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Geometry of the conv tower a kernel instantiation carries: kK taps, kCB blocks of
+// 32 hidden channels.  Tower<5, 1> is the reference's default net (training.py:134-136)
+// and the only one with per-equation kernels, resident weights and the rest of the
+// tuning above; the other towers (7 taps, 64 filters, 3 taps: hyper-parameters
+// create_hparams admits, model.py:455-458 builds whatever they say) run on the
+// run-time-parameterised kernels with the layer weights streamed from L2
+// (input_layer_big / hidden_layer_stream below).  Nets in between are embedded with
+// zero weights in the next tower up (capi.hip: embed_tower).
+template <int kK_, int kCB_>
+struct Tower {
+  static constexpr int kK = kK_;                    // conv taps (odd)
+  static constexpr int kCB = kCB_;                  // 32-channel blocks
+  static constexpr int kC = 32 * kCB_;              // hidden channels
+  static constexpr int kHS = kC + 4;                // padded activation row stride (floats):
+                                                    // (kC / 4 + 1) r mod 16 is a bijection on 16 rows
+  static constexpr int kInSteps = (kK_ + 2) / 2;    // (taps + bias) / 2, rounded up
+  static constexpr int kHidK = kK_ * kC / 2;        // 32x32x2 steps per output block (without bias)
+  static constexpr int kHidGroups = kHidK / 4;      // ... in groups of four (one float4 of weights)
+  static constexpr int kFinK = kK_ * kC + 1;        // 4x4x1 reduction steps of the output layer (+ bias)
+  static constexpr int kOperandGroups = kK_ * kC / 4;   // ds_read_b128 per lane in the output layer
+  static constexpr bool kDefault = kK_ == 5 && kCB_ == 1;
+  static_assert(kK_ % 2 == 1 && kK_ >= 3 && kK_ <= 7 && kCB_ >= 1 && kCB_ <= 2, "tower geometry");
+};
+typedef Tower<kKW, 1> DefaultTower;
+// floats of one hidden layer in the streamed layout: [group][out block][lane] float4, then the
+// bias rows [out block][lane]
+template <class TW>
+__host__ __device__ constexpr int stream_layer_floats() {
+  return TW::kHidGroups * TW::kCB * 64 * 4 + TW::kCB * 64;
+}
+template <class TW>
+__host__ __device__ constexpr int fin4_regs_t(int groups) { return (TW::kFinK * groups + 15) / 16; }
+
 // kRows = rows (grid points) per workgroup: 256 (four wavefronts, block
 // barriers between layers) or 64 (ONE wavefront owns whole samples, N <= 64:
 // no cross-wave dependency, wavefronts free-run and eight workgroups share a
 // CU).  Sizes are chosen so that 160 KiB of LDS hold 2 x 256-row or 8 x 64-row
 // workgroups.
-template <int kRows, int kWR = 64, bool kWide = false>
+template <int kRows, int kWR = 64, bool kWide = false, class TW = DefaultTower>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
   static constexpr int kFkMax = 3 * kRows / 4;  // samples * 12 harmonic sums (zero padded)
-  float hA[kRows * kHS];
-  float hB[kRows * kHS];
+  float hA[kRows * TW::kHS];
+  float hB[kRows * TW::kHS];
   float u[kRows];
   float un[kRows == kWR ? 1 : kRows];   // u / standard_deviation (input-layer operand; one-wave
                                         // groups feed the input layer by lane permutes)
@@ -78,6 +111,9 @@ static_assert(8 * sizeof(Shared<64>) <= 158 * 1024, "2 x four-group workgroups p
 static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
 static_assert(sizeof(Shared<64, 64, true>) <= 22 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
               "wide flavour: 7 x 64-row / 2 x 256-row workgroups per CU");
+static_assert(sizeof(Shared<64, 64, false, Tower<7, 2>>) <= 40 * 1024 &&
+              sizeof(Shared<256, 64, false, Tower<7, 2>>) <= 160 * 1024,
+              "64-filter towers: 4 x 64-row / 1 x 256-row workgroups per CU");
 
 // A one-wave row group (kRows == kWR) may be one of several INDEPENDENT groups
 // sharing a workgroup (substep_quad_kernel): its thread index is the lane, and
@@ -479,6 +515,191 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   }
 }
 
+// ---------------------------------------------------------------------------
+// Towers other than 5 taps x 32 channels (Tower<7, 1>, <5, 2>, <7, 2>, <3, 1>): the
+// same implicit GEMMs, generic in the tap count and in the number of 32-channel
+// blocks, with every layer's weights STREAMED from L2 in the order the MFMAs
+// consume them instead of living in registers (a 7-tap layer is 113 operand rows, a
+// 64-filter layer 320 per lane).  Activations: LDS rows of kC + 4 floats.
+// ---------------------------------------------------------------------------
+
+// Rows of grid points (pos - K/2 .. pos + K/2) mod N for tile row `trow`.
+template <class TW>
+__device__ __forceinline__ void tap_rows_n(const Lane& ln, int trow, int n, bool pow2,
+                                           int (&rows)[TW::kK]) {
+  constexpr int kLeft = TW::kK / 2;
+  if (pow2) {   // wave-uniform: samples start at multiples of N, no spare rows
+    const int mask = n - 1, base = trow & ~mask;
+#pragma unroll
+    for (int k = 0; k < TW::kK; ++k) rows[k] = ((trow + k - kLeft) & mask) | base;
+    return;
+  }
+  const int base = row_sample(trow, ln.inv_n) * n;
+  const int pos = trow - base;
+  const bool live = trow < ln.rows_used;   // spare rows read themselves
+#pragma unroll
+  for (int k = 0; k < TW::kK; ++k) {
+    int q = pos + k - kLeft;               // |k - kLeft| <= 3 < N (N >= 8)
+    q = q < 0 ? q + n : q;
+    q = q >= n ? q - n : q;
+    rows[k] = live ? base + q : trow;
+  }
+}
+
+// D of a 32x32 tile of output block `blk` -> LDS rows of stride HS floats.
+template <int HS>
+__device__ __forceinline__ void store_tile32_at(float* out, int trow, int blk, int half,
+                                                const f32x16& acc) {
+  float* orow = out + trow * HS + 32 * blk + 4 * half;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd)
+    *reinterpret_cast<float4*>(orow + 8 * qd) = make_float4(
+        acc[4 * qd + 0], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+}
+
+// Input layer 1 -> kC: (K + 1) / 2 steps per output block (K taps + the bias row).
+//   A (DevParams::w_input, [block][step][lane]): W1[out = 32 blk + (l & 31)][k = 2 s + (l >> 5)],
+//      k < K: tap k, k = K: bias
+//   B: un[(pos(l & 31) + k - K/2) mod N] for k < K, 1 for k = K
+// kShfl (one-wave groups): the operands come from the lanes' registers.
+template <class TW, int kWR, bool kShfl>
+__device__ __forceinline__ void input_layer_big(const DevParams& p, const Lane& ln,
+                                                const float* __restrict__ us, float un,
+                                                float* __restrict__ out,
+                                                const int (&rows)[2][TW::kK], int act) {
+  constexpr int kT = kWR / 32, kS = TW::kInSteps, kLast = TW::kK - 1;
+  const int j = ln.lane & 31, half = ln.lane >> 5;
+  float w[TW::kCB][kS];
+  const float* __restrict__ wsrc = p.w_input + opaque(ln.lane);
+#pragma unroll
+  for (int h = 0; h < TW::kCB; ++h)
+#pragma unroll
+    for (int s = 0; s < kS; ++s) w[h][s] = wsrc[(h * kS + s) * 64];
+  float b[kT][kS];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+#pragma unroll
+    for (int s = 0; s < kS; ++s) {
+      // taps 2 s / 2 s + 1 by half-wave; the last step pairs tap K - 1 with the bias row
+      const int r = (2 * s < kLast) ? (half ? rows[t][2 * s + 1 < TW::kK ? 2 * s + 1 : kLast]
+                                            : rows[t][2 * s])
+                                    : rows[t][kLast];
+      b[t][s] = kShfl ? __shfl(un, r, 64) : us[r];
+    }
+    b[t][kS - 1] = half ? 1.0f : b[t][kS - 1];
+  }
+#pragma unroll
+  for (int h = 0; h < TW::kCB; ++h) {
+    f32x16 acc[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kS; ++s)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[t] = DDD_MFMA32(w[h][s], b[t][s], acc[t]);
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      activate16(acc[t], act);
+      store_tile32_at<TW::kHS>(out, ln.wave * kWR + t * 32 + j, h, half, acc[t]);
+    }
+  }
+}
+
+// One hidden layer kC -> kC for this wave's two 32-row tiles.  Reduction step
+// s = (tap kCB + cb) 16 + jj pairs input channels 32 cb + jj (lower half-wave) and
+// 32 cb + 16 + jj (upper); four steps = one float4 of weights per output block
+// (DevParams::w_hidden: [layer][group][block][lane] float4, then the bias rows) and one
+// ds_read_b128 of activations per tile.  Weights are requested kAhead groups (8-16
+// MFMAs = 512-1024 cycles each) before their MFMAs, activations one group ahead.
+template <class TW, int kWR>
+__device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const Lane& ln,
+                                                    int hidden_index,
+                                                    const float* __restrict__ in,
+                                                    float* __restrict__ out,
+                                                    const int (&rows)[2][TW::kK], int act) {
+  constexpr int kT = kWR / 32, kCB = TW::kCB, kG = TW::kHidGroups, kAhead = 2;
+  const int j = ln.lane & 31, half = ln.lane >> 5;
+  int rowo[kT][TW::kK];
+#pragma unroll
+  for (int t = 0; t < kT; ++t)
+#pragma unroll
+    for (int k = 0; k < TW::kK; ++k)
+      rowo[t][k] = (int)__umul24((unsigned)rows[t][k], (unsigned)(TW::kHS * 4)) + 64 * half;
+  const auto operand = [&](int t, int g) {   // group g: tap g / (4 kCB), block (g / 4) % kCB, quad g % 4
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) +
+                                            rowo[t][g / (4 * kCB)] + 128 * ((g / 4) % kCB) +
+                                            16 * (g % 4));
+  };
+  const float* __restrict__ layer =
+      p.w_hidden + (size_t)hidden_index * stream_layer_floats<TW>();
+  const float4* __restrict__ wq = reinterpret_cast<const float4*>(layer) + opaque(ln.lane);
+  const float* __restrict__ wbias = layer + kG * kCB * 64 * 4 + opaque(ln.lane);
+  f32x16 acc[kCB][kT];
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.0f;
+  float4 wbuf[kAhead + 1][kCB], bbuf[2][kT];
+  float wb[kCB];
+#pragma unroll
+  for (int h = 0; h < kCB; ++h) wb[h] = wbias[h * 64];
+#pragma unroll
+  for (int g = 0; g < kAhead; ++g)
+#pragma unroll
+    for (int h = 0; h < kCB; ++h) wbuf[g][h] = wq[(g * kCB + h) * 64];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) bbuf[0][t] = operand(t, 0);
+#pragma unroll
+  for (int g = 0; g < kG; ++g) {
+    if (g + kAhead < kG) {
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+        wbuf[(g + kAhead) % (kAhead + 1)][h] = wq[((g + kAhead) * kCB + h) * 64];
+    }
+    if (g + 1 < kG) {
+#pragma unroll
+      for (int t = 0; t < kT; ++t) bbuf[(g + 1) & 1][t] = operand(t, g + 1);
+    }
+    const float4* wg = wbuf[g % (kAhead + 1)];
+    const float4* bg = bbuf[g & 1];
+#pragma unroll
+    for (int h = 0; h < kCB; ++h)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].x, bg[t].x, acc[h][t]);
+#pragma unroll
+    for (int h = 0; h < kCB; ++h)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].y, bg[t].y, acc[h][t]);
+#pragma unroll
+    for (int h = 0; h < kCB; ++h)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].z, bg[t].z, acc[h][t]);
+#pragma unroll
+    for (int h = 0; h < kCB; ++h)
+#pragma unroll
+      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].w, bg[t].w, acc[h][t]);
+    // schedule: the requests of later groups first, then this group's MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, (g + kAhead < kG) ? kCB : 0, 0);   // VMEM reads
+    __builtin_amdgcn_sched_group_barrier(0x100, (g + 1 < kG) ? kT : 0, 0);         // DS reads
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kCB * kT, 0);                  // MFMAs
+  }
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wb[h], 1.0f, acc[h][t]);   // bias row
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      activate16(acc[h][t], act);
+      store_tile32_at<TW::kHS>(out, ln.wave * kWR + t * 32 + j, h, half, acc[h][t]);
+    }
+}
+
 // Output layer (32 -> C_out <= 16, linear) on v_mfma_f32_4x4x1_16b_f32.  A
 // 16x16x4 formulation pads the 11-14 live output channels to 16 and leaves the
 // result in a (position, channel-quad) layout that has to travel through LDS to
@@ -503,8 +724,8 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, kAbid, 0);
 }
 
-template <int NG, int Q0, int... J>
-__device__ __forceinline__ void fin4_mfmas(const float (&w)[fin4_regs(NG)], const f32x4& b,
+template <int NG, int Q0, int NW, int... J>
+__device__ __forceinline__ void fin4_mfmas(const float (&w)[NW], const f32x4& b,
                                            f32x4 (&acc)[NG], std::integer_sequence<int, J...>) {
   ((acc[J % NG] = mfma4<(Q0 + J) % 16>(w[(Q0 + J) / 16], b[J / NG], acc[J % NG])), ...);
 }
@@ -517,45 +738,49 @@ __device__ __forceinline__ void load_final4(const DevParams& p, int lane,
 
 constexpr int kFin4Ahead = 2;   // operand groups in flight ahead of the MFMAs
 
-template <int NG, int OG>
-__device__ __forceinline__ void fin4_step(const char* __restrict__ in, const int (&off)[kKW],
-                                          const float (&w)[fin4_regs(NG)],
+// (TW: the tower -- K taps x C channels: K C / 4 operand groups of four channels,
+// C / 4 per tap row)
+template <int NG, int OG, class TW>
+__device__ __forceinline__ void fin4_step(const char* __restrict__ in, const int (&off)[TW::kK],
+                                          const float (&w)[fin4_regs_t<TW>(NG)],
                                           f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG]) {
   constexpr int kNext = OG + kFin4Ahead;
-  if constexpr (kNext < 40)
+  constexpr int kPerTap = TW::kC / 4;
+  if constexpr (kNext < TW::kOperandGroups)
     buf[kNext % (kFin4Ahead + 1)] =
-        *reinterpret_cast<const f32x4*>(in + off[kNext / 8] + 16 * (kNext % 8));
+        *reinterpret_cast<const f32x4*>(in + off[kNext / kPerTap] + 16 * (kNext % kPerTap));
   fin4_mfmas<NG, OG * 4 * NG>(w, buf[OG % (kFin4Ahead + 1)], acc,
                               std::make_integer_sequence<int, 4 * NG>{});
-  if constexpr (kNext < 40) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+  if constexpr (kNext < TW::kOperandGroups) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
   __builtin_amdgcn_sched_group_barrier(0x008, 4 * NG, 0);                        // MFMAs
 }
 
-template <int NG, int... OG>
-__device__ __forceinline__ void fin4_run(const char* __restrict__ in, const int (&off)[kKW],
-                                         const float (&w)[fin4_regs(NG)],
+template <int NG, class TW, int... OG>
+__device__ __forceinline__ void fin4_run(const char* __restrict__ in, const int (&off)[TW::kK],
+                                         const float (&w)[fin4_regs_t<TW>(NG)],
                                          f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG],
                                          std::integer_sequence<int, OG...>) {
-  (fin4_step<NG, OG>(in, off, w, buf, acc), ...);
+  (fin4_step<NG, OG, TW>(in, off, w, buf, acc), ...);
 }
 
-// `off`: LDS byte offsets (row * kHS * 4) of the lane's five tap rows.
-template <int NG>
+// `off`: LDS byte offsets (row * kHS * 4) of the lane's tap rows.
+template <int NG, class TW = DefaultTower>
 __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
-                                             const float (&w)[fin4_regs(NG)],
-                                             const int (&off)[kKW], f32x4 (&acc)[NG]) {
+                                             const float (&w)[fin4_regs_t<TW>(NG)],
+                                             const int (&off)[TW::kK], f32x4 (&acc)[NG]) {
   const char* __restrict__ in = reinterpret_cast<const char*>(in_f);
+  constexpr int kPerTap = TW::kC / 4;
   f32x4 buf[kFin4Ahead + 1];
 #pragma unroll
   for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int og = 0; og < kFin4Ahead; ++og)
-    buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / 8] + 16 * (og % 8));
+    buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / kPerTap] + 16 * (og % kPerTap));
   __builtin_amdgcn_sched_group_barrier(0x100, kFin4Ahead, 0);
-  fin4_run<NG>(in, off, w, buf, acc, std::make_integer_sequence<int, 40>{});
-  // bias row: k = 160 against a constant 1
-  fin4_mfmas<NG, 160 * NG>(w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc,
-                           std::make_integer_sequence<int, NG>{});
+  fin4_run<NG, TW>(in, off, w, buf, acc, std::make_integer_sequence<int, TW::kOperandGroups>{});
+  // bias row: k = K C against a constant 1
+  fin4_mfmas<NG, (TW::kFinK - 1) * NG>(w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc,
+                                       std::make_integer_sequence<int, NG>{});
 }
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
