@@ -178,6 +178,8 @@ struct ddd_model {
   float* d_w_final4 = nullptr;
   float* d_w_final4_rt = nullptr;
   bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
+  int tower_k = 5, tower_cb = 1;     // conv tower the MFMA kernels carry the net in (rhs_mfma.h Tower)
+  bool big() const { return tower_k != ddd::mfma::kKW || tower_cb != 1; }
   float4* d_frc = nullptr;
   float* d_sp = nullptr;
   float* d_trig = nullptr;
@@ -340,6 +342,52 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
   const ddd::DevParams& dp = m->dp;
   const float* weights = net.weights;
   const int hidden = dp.L - 2;
+  const int tk = m->tower_k, tcb = m->tower_cb, tc = 32 * tcb;   // the (padded) net: tk taps, tc filters
+  if (m->big()) {
+    // streamed layouts of rhs_mfma.h: input_layer_big / hidden_layer_stream
+    const int in_steps = (tk + 2) / 2;
+    {
+      const float* w = weights + net.w_off[0];   // [tk][1][tc]
+      const float* b = weights + net.b_off[0];
+      std::vector<float> packed((size_t)tcb * in_steps * 64, 0.0f);
+      for (int h = 0; h < tcb; ++h)
+        for (int s = 0; s < in_steps; ++s)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int k = 2 * s + (lane >> 5), ch = 32 * h + (lane & 31);
+            packed[((size_t)h * in_steps + s) * 64 + lane] =
+                k < tk ? w[k * tc + ch] : k == tk ? b[ch] : 0.0f;
+          }
+      int rc = upload(packed, &m->d_w_input);
+      if (rc) return rc;
+      m->dp.w_input = m->d_w_input;
+    }
+    if (hidden > 0) {
+      const int groups = tk * tc / 8;   // Tower::kHidGroups
+      const size_t layer_floats = (size_t)groups * tcb * 64 * 4 + (size_t)tcb * 64;
+      std::vector<float> packed((size_t)hidden * layer_floats, 0.0f);
+      for (int l = 0; l < hidden; ++l) {
+        const float* w = weights + net.w_off[l + 1];   // [tk][tc][tc]
+        const float* b = weights + net.b_off[l + 1];
+        float* dst = packed.data() + (size_t)l * layer_floats;
+        for (int g = 0; g < groups; ++g)
+          for (int h = 0; h < tcb; ++h)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 4; ++e) {
+                const int s = 4 * g + e;                       // reduction step of this output block
+                const int tap = s / (16 * tcb), cb = (s / 16) % tcb, jj = s % 16;
+                const int cin = 32 * cb + 16 * (lane >> 5) + jj, cout = 32 * h + (lane & 31);
+                dst[(((size_t)g * tcb + h) * 64 + lane) * 4 + e] =
+                    w[((size_t)tap * tc + cin) * tc + cout];
+              }
+        float* bias = dst + (size_t)groups * tcb * 64 * 4;
+        for (int h = 0; h < tcb; ++h)
+          for (int lane = 0; lane < 32; ++lane) bias[h * 64 + lane] = b[32 * h + lane];
+      }
+      int rc = upload(packed, &m->d_w_hidden);
+      if (rc) return rc;
+      m->dp.w_hidden = m->d_w_hidden;
+    }
+  } else {
   {
     // input layer 1 -> 32: k = 2 s + (lane >> 5) is the tap, k = 5 the bias
     const float* w = weights + net.w_off[0];   // [5][1][32]
@@ -380,8 +428,12 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     if (rc) return rc;
     m->dp.w_hidden = m->d_w_hidden;
   }
+  }   // default tower
   {
     const int l = dp.L - 1;
+    const int kc = tk * tc;                      // reduction length of the output layer
+    const int fin_k = kc + 1;                    // ... + the bias row (Tower::kFinK)
+    const auto fin_regs = [fin_k](int groups) { return (fin_k * groups + 15) / 16; };
     const float* w_nat = weights + net.w_off[l];   // [5][32][C_out]
     const float* b_nat = weights + net.b_off[l];
     // Fold coeff = bias + net[start:stop] @ nullspace into the output layer:
@@ -401,25 +453,25 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
       // the net emits the D x G coefficients themselves (model.py:460-475) in
       // exactly the folded layer's channel order: nothing to project
       can_fold = true;
-      wf.assign((size_t)5 * 32 * 16, 0.0f);
+      wf.assign((size_t)kc * 16, 0.0f);
       bf.assign(16, 0.0f);
       for (int c = 0; c < dp.D * dp.G; ++c) {
-        for (int tc = 0; tc < 5 * 32; ++tc)
-          wf[(size_t)tc * 16 + c] = w_nat[(size_t)tc * dp.C_out + c];
+        for (int row = 0; row < kc; ++row)
+          wf[(size_t)row * 16 + c] = w_nat[(size_t)row * dp.C_out + c];
         bf[c] = b_nat[c];
       }
     } else if (can_fold) {
-      wf.assign((size_t)5 * 32 * 16, 0.0f);
+      wf.assign((size_t)kc * 16, 0.0f);
       bf.assign(16, 0.0f);
       for (int d = 0; d < dp.D; ++d)
         for (int g = 0; g < dp.G; ++g) {
           const int oc = dp.G * d + g;
-          for (int tc = 0; tc < 5 * 32; ++tc) {
+          for (int row = 0; row < kc; ++row) {
             double acc = 0.0;
             for (int j = 0; j < dp.in_size[d]; ++j)
-              acc += (double)w_nat[(size_t)tc * dp.C_out + dp.in_start[d] + j] *
+              acc += (double)w_nat[(size_t)row * dp.C_out + dp.in_start[d] + j] *
                      (double)dp.ns8[dp.in_start[d] + j][g];
-            wf[(size_t)tc * 16 + oc] = (float)acc;
+            wf[(size_t)row * 16 + oc] = (float)acc;
           }
           // bias row of the folded layer: the accuracy layer's standard
           // coefficients + the projected conv bias, rounded once
@@ -478,18 +530,18 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
       // rows), then the pairs (fin4_regs(2) rows each); + slack so that the
       // kernels' fixed-size first fetch (fin4_regs(3) rows) stays inside
       const int groups = m->dp.rt_groups, head = ddd::mfma::rt_head_groups(groups);
-      const int pair_rows = ddd::mfma::fin4_regs(2), head_rows = ddd::mfma::fin4_regs(head);
-      const int total_rows = head_rows + (groups - head) / 2 * pair_rows + ddd::mfma::fin4_regs(3);
+      const int pair_rows = fin_regs(2), head_rows = fin_regs(head);
+      const int total_rows = head_rows + (groups - head) / 2 * pair_rows + fin_regs(3);
       std::vector<float> packed((size_t)total_rows * 64, 0.0f);
       const auto pack_chunk = [&](int row0, int first_group, int ng) {
-        for (int k = 0; k < ddd::mfma::kFin4K; ++k)
+        for (int k = 0; k < fin_k; ++k)
           for (int gi = 0; gi < ng; ++gi) {
             const int q = k * ng + gi;
             for (int r = 0; r < 4; ++r) {
               const int ch = 4 * (first_group + gi) + r;
               if (ch >= cout_n) continue;
               packed[((size_t)row0 + q / 16) * 64 + 4 * (q % 16) + r] =
-                  k < 160 ? w[(size_t)k * cout_n + ch] : b[ch];
+                  k < kc ? w[(size_t)k * cout_n + ch] : b[ch];
             }
           }
       };
@@ -506,7 +558,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     const int groups_folded = (dp.D * dp.G + 3) / 4, groups_plain = (dp.C_out + 3) / 4;
     m->spec_folded = can_fold && groups_folded <= groups_plain;
     m->dp.fin4_groups = m->spec_folded ? groups_folded : groups_plain;
-    if (!m->wide) {   // (the specialised kernels never serve a wide model)
+    if (!m->wide && !m->big()) {   // (the specialised kernels: default tower, not wide)
       rc = upload(quad_rows(pack4(m->dp.fin4_groups, m->spec_folded, true).data(),
                             ddd::mfma::fin4_regs(4)),
                   &m->d_w_final4);
@@ -517,7 +569,8 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
   return DDD_OK;
 }
 
-// Smaller towers ride the 5-tap x 32-channel MFMA layers EXACTLY, embedded with
+// Nets between two towers ride the next tower up EXACTLY (rhs_mfma.h: Tower; the
+// default one has 5 taps x 32 channels), embedded with
 // zero weights: a K-tap kernel (K < 5) is the 5-tap kernel whose outer taps are
 // zero (tap k of K sits at offset k - ceil((K-1)/2), the alignment of
 // layers.pad_periodic(center=True), layers.py:76-79), F < 32 filters are 32
@@ -527,10 +580,10 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
 // bit-identical to the unpadded evaluation order-for-order; the matrix work
 // grows by 5/K and (32/F)^2, still an order of magnitude ahead of the generic
 // kernel.  (Algorithmic FLOPs -- ddd_fma_per_point -- keep counting the true net.)
-void embed_small_tower(const ddd::DevParams& dp, const std::vector<float>& wv,
-                       std::vector<float>* padded, NetLayout* net) {
-  const int k5 = ddd::mfma::kKW, f32 = ddd::mfma::kF;
-  const int shift = (k5 - 1) / 2 - dp.K / 2;   // ceil((5-1)/2) - ceil((K-1)/2)
+void embed_tower(const ddd::DevParams& dp, const std::vector<float>& wv, int tower_k,
+                 int tower_c, std::vector<float>* padded, NetLayout* net) {
+  const int k5 = tower_k, f32 = tower_c;       // (the tower's taps and filters)
+  const int shift = (k5 - 1) / 2 - dp.K / 2;   // ceil((k5-1)/2) - ceil((K-1)/2), k5 odd
   padded->clear();
   for (int l = 0; l < dp.L; ++l) {
     const int cin = l == 0 ? 1 : f32;
@@ -572,11 +625,20 @@ void decide_mfma(ddd_model* m) {
     // no projection) run on the run-time-parameterised MFMA kernels
     if (dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0 && dp.D > 2) wide = true;
     if (dp.C_out > ddd::kChMax) wide = true;
-    if (dp.F > ddd::mfma::kF) no("filter_size > 32");         // (smaller towers are packed
-    if (dp.K > ddd::mfma::kKW) no("kernel_size > 5");         //  zero-padded: embed_small_tower)
+    // the smallest tower built that holds the net (launch.h: DDD_FOR_EACH_BIG_TOWER + the
+    // default 5 x 32); nets in between are packed zero-padded (embed_tower)
+    m->tower_k = dp.K <= 3 ? 3 : dp.K <= 5 ? 5 : 7;
+    m->tower_cb = dp.F <= 32 ? 1 : 2;
+    if (dp.F > 64) no("filter_size > 64");
+    if (dp.K > 7) no("kernel_size > 7");
+    if (dp.K > 5 && dp.F > 32) no("kernel_size > 5 together with filter_size > 32");
     if (dp.L < 2) no("fewer than 2 conv layers");
     if (dp.C_out > ddd::kChWide) no("more than 24 output channels");
+    // stencils > 8 points / > 16 channels exist on the 5 x 32 tower only (wide flavour)
+    if (wide && m->tower_k == 3) m->tower_k = 5;
+    if (wide && m->big()) no("wide stencils / > 16 output channels with a tower other than 5 x 32");
   }
+  if (!ok || dp.fixed) { m->tower_k = 5; m->tower_cb = 1; }
   m->wide = ok && wide;
   m->mfma_ok = ok;
   m->mfma_reason = why;
@@ -657,7 +719,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   const bool fits64 = m->dp.N <= 64 && 64 % m->dp.N == 0;
   if (m->force_rows == 256 || !fits64) return {256, 64};
   if (m->force_rows == 64) return {64, 64};
-  if (m->force_rows == 32 && !m->wide) return {64, 32};   // (no wide two-wave split)
+  if (m->force_rows == 32 && !m->wide && !m->big()) return {64, 32};   // (no wide / other-tower split)
   // Measured on MI355X (profiles/r1_ablation.txt): two 32-row wavefronts per
   // SIMD are slower than one 64-row wavefront even when the batch leaves half
   // the wave slots empty (B = 1024: 73.6 vs 82.1 TFLOP/s), so the split is
@@ -671,7 +733,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
 // width, projection folded when D <= 2) on a non-Godunov equation.
 int spec_equation(const ddd_model* m, int rows) {
   const ddd::DevParams& dp = m->dp;
-  if (g_debug.no_spec || m->wide) return -1;
+  if (g_debug.no_spec || m->wide || m->big()) return -1;
   if (dp.forced) {
     // the specialised kernels only carry the harmonic-sum forcing (rhs_mfma.h:
     // launch_setup `fast`); exotic tables go to the run-time kernels
@@ -760,7 +822,15 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
       DDD_SUBSTEP_CASE(ddd::EQ_KS)
       DDD_SUBSTEP_CASE(ddd::EQ_KS_CONS)
       default:
-        if (m->wide) {
+        if (m->big()) {
+#define DDD_BIG_SUBSTEP(K, CB)                                                          \
+          if (m->tower_k == K && m->tower_cb == CB) {                                   \
+            if (geo.rows == 64) ddd::launch::substep_big_unit<K, CB, 64>(dp, a, blocks, stream); \
+            else ddd::launch::substep_big_unit<K, CB, 256>(dp, a, blocks, stream);      \
+          }
+          DDD_FOR_EACH_BIG_TOWER(DDD_BIG_SUBSTEP)
+#undef DDD_BIG_SUBSTEP
+        } else if (m->wide) {
           if (geo.rows == 64) ddd::launch::substep_wide_unit<64>(dp, a, blocks, stream);
           else ddd::launch::substep_wide_unit<256>(dp, a, blocks, stream);
         } else {
@@ -813,6 +883,16 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
     default: break;
   }
 #undef DDD_SPEC_CASE
+  if (m->big()) {
+    if constexpr (kWR == 64) {
+#define DDD_BIG_INTEGRATE(K, CB)                                                         \
+      if (m->tower_k == K && m->tower_cb == CB)                                          \
+        ddd::launch::integrate_big_unit<K, CB, kRows, f64>(m->dp, a, blocks, stream);
+      DDD_FOR_EACH_BIG_TOWER(DDD_BIG_INTEGRATE)
+#undef DDD_BIG_INTEGRATE
+    }
+    return;
+  }
   if (m->wide) {
     if (kWR == 64) ddd::launch::integrate_wide_unit<kRows, f64 ? 1 : 0>(hoist, m->dp, a, blocks,
                                                                         stream);
@@ -1136,7 +1216,8 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
         NetLayout net;
         net.weights = wv.data();
         for (int l = 0; l < dp.L; ++l) { net.w_off[l] = dp.w_off[l]; net.b_off[l] = dp.b_off[l]; }
-        if (dp.K != ddd::mfma::kKW || dp.F != ddd::mfma::kF) embed_small_tower(dp, wv, &padded, &net);
+        if (dp.K != m->tower_k || dp.F != 32 * m->tower_cb)
+          embed_tower(dp, wv, m->tower_k, 32 * m->tower_cb, &padded, &net);
         rc = pack_mfma_weights(m, net);
       }
     }
@@ -1768,7 +1849,15 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     DDD_ADAPTIVE_CASE(ddd::EQ_KS_CONS)
 #undef DDD_ADAPTIVE_CASE
     default:
-      if (m->wide) {
+      if (m->big()) {
+#define DDD_BIG_ADAPTIVE(K, CB)                                                           \
+        if (m->tower_k == K && m->tower_cb == CB) {                                       \
+          if (geo.rows == 64) ddd::launch::adaptive_big_unit<K, CB, 64>(m->dp, a, blocks, stream); \
+          else ddd::launch::adaptive_big_unit<K, CB, 256>(m->dp, a, blocks, stream);      \
+        }
+        DDD_FOR_EACH_BIG_TOWER(DDD_BIG_ADAPTIVE)
+#undef DDD_BIG_ADAPTIVE
+      } else if (m->wide) {
         if (geo.rows == 64) ddd::launch::adaptive_wide_unit<64>(m->dp, a, blocks, stream);
         else ddd::launch::adaptive_wide_unit<256>(m->dp, a, blocks, stream);
       } else if (geo.rows == 64) {
@@ -1912,9 +2001,10 @@ int ddd_set_kernel(ddd_model* m, int kind) {
       if (!m->mfma_ok)
         return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
                     m->mfma_reason.c_str());
-      if (kind == DDD_KERNEL_MFMA_ROWS64_W32 && m->wide)
+      if (kind == DDD_KERNEL_MFMA_ROWS64_W32 && (m->wide || m->big()))
         return fail(DDD_ERR_UNSUPPORTED,
-                    "the two-wave split has no wide (stencil > 8 / > 16 channels) instantiation");
+                    "the two-wave split exists for the 5-tap x 32-filter tower with stencils <= 8 "
+                    "points / <= 16 channels only");
       if ((kind == DDD_KERNEL_MFMA_ROWS64 || kind == DDD_KERNEL_MFMA_ROWS64_W32) &&
           !(m->dp.N <= 64 && 64 % m->dp.N == 0))
         return fail(DDD_ERR_UNSUPPORTED,

@@ -99,6 +99,31 @@ DDD_DECLARE_WIDE(64)
 DDD_DECLARE_WIDE(256)
 #undef DDD_DECLARE_WIDE
 
+// towers other than 5 taps x 32 channels (rhs_mfma.h: Tower<kK, kCB>), one kernel per
+// unit: mfma_big.hip.  kRows: 64 or 256.
+template <int kK, int kCB, int kRows, bool kF64>
+void integrate_big_unit(const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream);
+template <int kK, int kCB, int kRows>
+void substep_big_unit(const DevParams& p, const SubstepArgs& a, int blocks, hipStream_t stream);
+template <int kK, int kCB, int kRows>
+void adaptive_big_unit(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
+#define DDD_DECLARE_BIG_ROWS(K, CB, ROWS)                                                       \
+  template <> void integrate_big_unit<K, CB, ROWS, false>(const DevParams&, const IntegrateArgs&, \
+                                                          int, hipStream_t);                     \
+  template <> void integrate_big_unit<K, CB, ROWS, true>(const DevParams&, const IntegrateArgs&,  \
+                                                         int, hipStream_t);                      \
+  template <> void substep_big_unit<K, CB, ROWS>(const DevParams&, const SubstepArgs&, int,      \
+                                                 hipStream_t);                                   \
+  template <> void adaptive_big_unit<K, CB, ROWS>(const DevParams&, const AdaptiveArgs&, int,    \
+                                                  hipStream_t);
+#define DDD_DECLARE_BIG(K, CB) DDD_DECLARE_BIG_ROWS(K, CB, 64) DDD_DECLARE_BIG_ROWS(K, CB, 256)
+// the towers built (capi.hip: pick_tower embeds a net in the smallest one that holds it;
+// 7 taps x 64 filters is not built: its unrolled layers take > 20 minutes to compile)
+#define DDD_FOR_EACH_BIG_TOWER(X) X(3, 1) X(7, 1) X(5, 2)
+DDD_FOR_EACH_BIG_TOWER(DDD_DECLARE_BIG)
+#undef DDD_DECLARE_BIG
+#undef DDD_DECLARE_BIG_ROWS
+
 inline void integrate_runtime(int rows, int wave_rows, bool f64, bool hoist, const DevParams& p,
                               const IntegrateArgs& a, int blocks, hipStream_t stream) {
   if (rows == 64 && wave_rows == 64) {

@@ -107,12 +107,12 @@ static_assert(sizeof(Shared<64>) + sizeof(AdaptiveShared<64>) <= 20 * 1024, "8 g
 template <int kRows>
 constexpr bool adaptive_lean() { return ((kRows == 64 ? 1 : 2) & DDD_ADAPTIVE_LEAN) != 0; }
 
-template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams p,
-                                                                       AdaptiveArgs a) {
-  __shared__ Shared<kRows, kWR, kWide> sm;
+template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false, class TW = DefaultTower>
+__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void adaptive_kernel(DevParams p,
+                                                                                 AdaptiveArgs a) {
+  __shared__ Shared<kRows, kWR, kWide, TW> sm;
   __shared__ AdaptiveShared<kRows> as;
-  static_assert(kRows == kWR || kWide ||
+  static_assert(kRows == kWR || kWide || !TW::kDefault ||
                     sizeof(Shared<kRows, kWR, kWide>) + sizeof(AdaptiveShared<kRows>) <= 80 * 1024,
                 "two 256-row workgroups per CU");
   // reduction scratch of sample_sum: one-wave groups shuffle; four-wave groups use
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void adaptive_kernel(DevParams
       if (!sums_ready) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)ft_now, tid);
       tn_lane = (float)ft_next;
     }
-    const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>()>(
+    const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>(), TW>(
         p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
     sums_ready = ahead;
     // (eval_rhs's barriers are compiler barriers too: this is a fresh read)

@@ -611,92 +611,114 @@ __device__ __forceinline__ void input_layer_big(const DevParams& p, const Lane& 
 // s = (tap kCB + cb) 16 + jj pairs input channels 32 cb + jj (lower half-wave) and
 // 32 cb + 16 + jj (upper); four steps = one float4 of weights per output block
 // (DevParams::w_hidden: [layer][group][block][lane] float4, then the bias rows) and one
-// ds_read_b128 of activations per tile.  Weights are requested kAhead groups (8-16
-// MFMAs = 512-1024 cycles each) before their MFMAs, activations one group ahead.
+// ds_read_b128 of activations per tile.  Weights are requested kStreamAhead groups
+// (8-16 MFMAs = 512-1024 cycles each) before their MFMAs, activations one group ahead.
+constexpr int kStreamAhead = 2;
+
+template <class TW, int kT>
+struct StreamState {
+  f32x16 acc[TW::kCB][kT];
+  float4 wbuf[kStreamAhead + 1][TW::kCB];
+  float4 bbuf[2][kT];
+  int rowo[kT][TW::kK];              // LDS byte offsets of the operand rows (+ 64 half)
+  const float4* __restrict__ wq;     // this lane's weight stream
+  const char* __restrict__ in;
+};
+
+// operand group g: tap g / (4 kCB), input block (g / 4) % kCB, quad g % 4
+template <class TW, int kT, int G>
+__device__ __forceinline__ float4 stream_operand(const StreamState<TW, kT>& st, int t) {
+  return *reinterpret_cast<const float4*>(st.in + st.rowo[t][G / (4 * TW::kCB)] +
+                                          128 * ((G / 4) % TW::kCB) + 16 * (G % 4));
+}
+
+template <class TW, int kT, int G>
+__device__ __forceinline__ void stream_group(StreamState<TW, kT>& st) {
+  constexpr int kCB = TW::kCB, kG = TW::kHidGroups;
+  if constexpr (G + kStreamAhead < kG) {
+#pragma unroll
+    for (int h = 0; h < kCB; ++h)
+      st.wbuf[(G + kStreamAhead) % (kStreamAhead + 1)][h] = st.wq[((G + kStreamAhead) * kCB + h) * 64];
+  }
+  if constexpr (G + 1 < kG) {
+#pragma unroll
+    for (int t = 0; t < kT; ++t) st.bbuf[(G + 1) & 1][t] = stream_operand<TW, kT, G + 1>(st, t);
+  }
+  const float4* wg = st.wbuf[G % (kStreamAhead + 1)];
+  const float4* bg = st.bbuf[G & 1];
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wg[h].x, bg[t].x, st.acc[h][t]);
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wg[h].y, bg[t].y, st.acc[h][t]);
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wg[h].z, bg[t].z, st.acc[h][t]);
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wg[h].w, bg[t].w, st.acc[h][t]);
+  // schedule: the requests of later groups first, then this group's MFMAs
+  if constexpr (G + kStreamAhead < kG) __builtin_amdgcn_sched_group_barrier(0x020, kCB, 0);   // VMEM reads
+  if constexpr (G + 1 < kG) __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);              // DS reads
+  __builtin_amdgcn_sched_group_barrier(0x008, 4 * kCB * kT, 0);                              // MFMAs
+}
+
+template <class TW, int kT, int... G>
+__device__ __forceinline__ void stream_groups(StreamState<TW, kT>& st,
+                                              std::integer_sequence<int, G...>) {
+  (stream_group<TW, kT, G>(st), ...);
+}
+
 template <class TW, int kWR>
 __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const Lane& ln,
                                                     int hidden_index,
                                                     const float* __restrict__ in,
                                                     float* __restrict__ out,
                                                     const int (&rows)[2][TW::kK], int act) {
-  constexpr int kT = kWR / 32, kCB = TW::kCB, kG = TW::kHidGroups, kAhead = 2;
+  constexpr int kT = kWR / 32, kCB = TW::kCB, kG = TW::kHidGroups;
   const int j = ln.lane & 31, half = ln.lane >> 5;
-  int rowo[kT][TW::kK];
+  StreamState<TW, kT> st;
 #pragma unroll
   for (int t = 0; t < kT; ++t)
 #pragma unroll
     for (int k = 0; k < TW::kK; ++k)
-      rowo[t][k] = (int)__umul24((unsigned)rows[t][k], (unsigned)(TW::kHS * 4)) + 64 * half;
-  const auto operand = [&](int t, int g) {   // group g: tap g / (4 kCB), block (g / 4) % kCB, quad g % 4
-    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(in) +
-                                            rowo[t][g / (4 * kCB)] + 128 * ((g / 4) % kCB) +
-                                            16 * (g % 4));
-  };
+      st.rowo[t][k] = (int)__umul24((unsigned)rows[t][k], (unsigned)(TW::kHS * 4)) + 64 * half;
+  st.in = reinterpret_cast<const char*>(in);
   const float* __restrict__ layer =
       p.w_hidden + (size_t)hidden_index * stream_layer_floats<TW>();
-  const float4* __restrict__ wq = reinterpret_cast<const float4*>(layer) + opaque(ln.lane);
+  st.wq = reinterpret_cast<const float4*>(layer) + opaque(ln.lane);
   const float* __restrict__ wbias = layer + kG * kCB * 64 * 4 + opaque(ln.lane);
-  f32x16 acc[kCB][kT];
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
 #pragma unroll
     for (int t = 0; t < kT; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.0f;
-  float4 wbuf[kAhead + 1][kCB], bbuf[2][kT];
+      for (int r = 0; r < 16; ++r) st.acc[h][t][r] = 0.0f;
   float wb[kCB];
 #pragma unroll
   for (int h = 0; h < kCB; ++h) wb[h] = wbias[h * 64];
 #pragma unroll
-  for (int g = 0; g < kAhead; ++g)
+  for (int g = 0; g < kStreamAhead; ++g)
 #pragma unroll
-    for (int h = 0; h < kCB; ++h) wbuf[g][h] = wq[(g * kCB + h) * 64];
+    for (int h = 0; h < kCB; ++h) st.wbuf[g][h] = st.wq[(g * kCB + h) * 64];
 #pragma unroll
-  for (int t = 0; t < kT; ++t) bbuf[0][t] = operand(t, 0);
-#pragma unroll
-  for (int g = 0; g < kG; ++g) {
-    if (g + kAhead < kG) {
-#pragma unroll
-      for (int h = 0; h < kCB; ++h)
-        wbuf[(g + kAhead) % (kAhead + 1)][h] = wq[((g + kAhead) * kCB + h) * 64];
-    }
-    if (g + 1 < kG) {
-#pragma unroll
-      for (int t = 0; t < kT; ++t) bbuf[(g + 1) & 1][t] = operand(t, g + 1);
-    }
-    const float4* wg = wbuf[g % (kAhead + 1)];
-    const float4* bg = bbuf[g & 1];
-#pragma unroll
-    for (int h = 0; h < kCB; ++h)
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].x, bg[t].x, acc[h][t]);
-#pragma unroll
-    for (int h = 0; h < kCB; ++h)
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].y, bg[t].y, acc[h][t]);
-#pragma unroll
-    for (int h = 0; h < kCB; ++h)
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].z, bg[t].z, acc[h][t]);
-#pragma unroll
-    for (int h = 0; h < kCB; ++h)
-#pragma unroll
-      for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].w, bg[t].w, acc[h][t]);
-    // schedule: the requests of later groups first, then this group's MFMAs
-    __builtin_amdgcn_sched_group_barrier(0x020, (g + kAhead < kG) ? kCB : 0, 0);   // VMEM reads
-    __builtin_amdgcn_sched_group_barrier(0x100, (g + 1 < kG) ? kT : 0, 0);         // DS reads
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * kCB * kT, 0);                  // MFMAs
-  }
+  for (int t = 0; t < kT; ++t) st.bbuf[0][t] = stream_operand<TW, kT, 0>(st, t);
+  stream_groups<TW, kT>(st, std::make_integer_sequence<int, kG>{});
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
 #pragma unroll
-    for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wb[h], 1.0f, acc[h][t]);   // bias row
+    for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wb[h], 1.0f, st.acc[h][t]);   // bias row
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
-      activate16(acc[h][t], act);
-      store_tile32_at<TW::kHS>(out, ln.wave * kWR + t * 32 + j, h, half, acc[h][t]);
+      activate16(st.acc[h][t], act);
+      store_tile32_at<TW::kHS>(out, ln.wave * kWR + t * 32 + j, h, half, st.acc[h][t]);
     }
 }
 
@@ -816,8 +838,8 @@ struct Resident {
 // at the start of the evaluation that uses it.  Inside an evaluation the two
 // phases sit at the input->hidden and hidden->output layer boundaries, where
 // the wavefront otherwise only waits for its activations to land in LDS.
-template <int kRows, int kWR, bool kWide>
-__device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kWide, class TW>
+__device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                                const Resident& res, float t, int tid) {
   if (tid < (kRows / p.N) * p.P) {
     float sn, cs;
@@ -831,8 +853,8 @@ __device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows,
 // acc + v and fma(v, 0, acc) is acc for every finite v (the staged values are
 // a sin / a cos of finite angles, the padding is zeroed at setup), so both
 // forms give the same bits.
-template <int kRows, int kWR, bool kMasked = false, bool kWide = false>
-__device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR, kWide>& sm, const Resident& res) {
+template <int kRows, int kWR, bool kMasked = false, bool kWide = false, class TW = DefaultTower>
+__device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR, kWide, TW>& sm, const Resident& res) {
   const int cnt = (res.frc_run >> 16) & 0xff;
   const float* __restrict__ pm = reinterpret_cast<const float*>(sm.pm) + (res.frc_run & 0xffff);
   float acc = 0.0f;
@@ -860,8 +882,8 @@ __device__ __forceinline__ float forcing_phase2(Shared<kRows, kWR, kWide>& sm, c
 
 // (kMasked: forcing_phase2's masked first trip -- the same bits, a third of the
 // instructions; needs Resident::frc_mask, i.e. apply_samples.)
-template <int kRows, int kWR, bool kMasked = false, bool kWide = false>
-__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kMasked = false, bool kWide = false, class TW = DefaultTower>
+__device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               const Resident& res, float t, int tid) {
   forcing_phase1<kRows, kWR>(p, sm, res, t, tid);
   group_barrier<kRows, kWR>();
@@ -882,8 +904,9 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 // kLean (adaptive integrators): the output layer's weights and the cos / sin table
 // are NOT kept resident (fetched from L2 / the LDS row padding per evaluation like
 // the run-time kernels do): 31-43 VGPRs the controller state needs.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide, bool kLean = false>
-__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR, kWide>& sm, int batch,
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide, bool kLean = false,
+          class TW = DefaultTower>
+__device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
                                           bool fast_forcing, float* derivs_out,
                                           float* coeffs_out, bool prepare_next = true,
@@ -922,6 +945,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   constexpr int kGW = flavour_stencil(kWide);    // stencil columns carried
   constexpr int kCh = flavour_channels(kWide);   // output channels carried
   static_assert(!(kSpec && kWide), "the per-equation kernels have no wide flavour");
+  static_assert(TW::kDefault || (!kSpec && !kWide && !kHoist && kWR == 64),
+                "towers other than 5 taps x 32 channels: run-time-parameterised kernels only");
   // 64-row-wavefront integrators with one hidden layer keep the loop-invariant
   // LDS offsets / permute addresses / patch indices in registers (kKeepOffsets);
   // the per-equation ones also the output layer's weights and the grid point's
@@ -934,9 +959,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   if (ln.owner) sm.u[ln.row] = u;
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
-  int hid_rows[2][kKW];
+  int hid_rows[2][TW::kK];
   if (!fixed) {
-    if (kKeepOffsets) {
+    if constexpr (!TW::kDefault) {
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+        tap_rows_n<TW>(ln, ln.wave * kWR + t2 * 32 + (ln.lane & 31), p.N, pow2, hid_rows[t2]);
+    } else if constexpr (kKeepOffsets) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
 #pragma unroll
@@ -991,17 +1020,25 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   for (int c = 0; c < kCh; ++c) net[c] = 0.0f;
   if (!fixed) {
     DDD_STAMP(1);
-    if (!(ablate & 16))
+    if constexpr (!TW::kDefault) {
+      input_layer_big<TW, kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, hid_rows, act);
+    } else if (!(ablate & 16)) {
       input_layer<kWR, kOneWave, kKeepOffsets>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows,
                                                act, res.in_perm);
+    }
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     float* in = sm.hA;
     float* out = sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
-      if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
-      group_barrier<kRows, kWR>();
-      hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act);
+      if constexpr (!TW::kDefault) {
+        group_barrier<kRows, kWR>();
+        hidden_layer_stream<TW, kWR>(p, ln, l - 1, in, out, hid_rows, act);
+      } else {
+        if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
+        group_barrier<kRows, kWR>();
+        hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act);
+      }
       float* tmp = in; in = out; out = tmp;
     }
     DDD_STAMP(2);
@@ -1009,7 +1046,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // output layer: weights resident (specialised one-wave integrators) or
       // fetched from L2 here, in flight across the forcing sums below
       // (run-time kernels: the first chunk, up to three groups)
-      constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs(3);
+      constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs_t<TW>(3);
       float wf4[kFirstRows];
       if (!kKeepRows) {
         if constexpr (kSpec) {
@@ -1020,12 +1057,18 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
           for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = wsrc[s2 * 64];
         }
       }
-      int off4[kKW];
-      if (kKeepRows) {
+      int off4[TW::kK];
+      if constexpr (kKeepRows) {
 #pragma unroll
         for (int s2 = 0; s2 < kFirstRows; ++s2) wf4[s2] = res.w_fin4[s2];
       }
-      if (kKeepOffsets) {
+      if constexpr (!TW::kDefault) {
+        int rows_k[TW::kK];
+        tap_rows_n<TW>(ln, ln.row, p.N, pow2, rows_k);
+#pragma unroll
+        for (int k = 0; k < TW::kK; ++k)
+          off4[k] = (int)__umul24((unsigned)rows_k[k], (unsigned)(TW::kHS * 4));
+      } else if constexpr (kKeepOffsets) {
 #pragma unroll
         for (int k = 0; k < kKW; ++k) off4[k] = res.fin4_off[k];
       } else {
@@ -1063,14 +1106,14 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
         // then pairs -- a net with 8 channels issues half the matrix work of one
         // with 16 instead of the same.  Wave-uniform branches; every chunk's
         // weights are fetched while the previous chunk's MFMAs run.
-        constexpr int kPairRows = fin4_regs(2);
+        constexpr int kPairRows = fin4_regs_t<TW>(2);
         const int head = rt_head_groups(rt_groups);
         int done = 0;   // groups issued so far
         if (!(ablate & 4)) {
           float wnext[kPairRows];
           const auto fetch_pair = [&](int first_group) {
             const float* __restrict__ wn = p.w_final4_rt +
-                (size_t)(fin4_regs(head) + (first_group - head) / 2 * kPairRows) * 64 +
+                (size_t)(fin4_regs_t<TW>(head) + (first_group - head) / 2 * kPairRows) * 64 +
                 opaque(ln.lane);
 #pragma unroll
             for (int s2 = 0; s2 < kPairRows; ++s2) wnext[s2] = wn[s2 * 64];
@@ -1078,17 +1121,17 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
           if (head > 0 && head < rt_groups) fetch_pair(head);   // (head 0: pair 0 is in wf4)
           if (head == 3) {
             f32x4 acc3[3];
-            final_layer4<3>(in, wf4, off4, acc3);
+            final_layer4<3, TW>(in, wf4, off4, acc3);
 #pragma unroll
             for (int g4 = 0; g4 < 3; ++g4)
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) net[4 * g4 + r4] = acc3[g4][r4];
           } else if (head == 1) {
-            float w1[fin4_regs(1)];
+            float w1[fin4_regs_t<TW>(1)];
 #pragma unroll
-            for (int s2 = 0; s2 < fin4_regs(1); ++s2) w1[s2] = wf4[s2];
+            for (int s2 = 0; s2 < fin4_regs_t<TW>(1); ++s2) w1[s2] = wf4[s2];
             f32x4 acc1[1];
-            final_layer4<1>(in, w1, off4, acc1);
+            final_layer4<1, TW>(in, w1, off4, acc1);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) net[r4] = acc1[0][r4];
           }
@@ -1102,7 +1145,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
             for (int s2 = 0; s2 < kPairRows; ++s2) w2[s2] = (head == 0 && j == 0) ? wf4[s2] : wnext[s2];
             if (done + 2 < rt_groups) fetch_pair(done + 2);
             f32x4 acc2[2];
-            final_layer4<2>(in, w2, off4, acc2);
+            final_layer4<2, TW>(in, w2, off4, acc2);
             if (head == 0) {
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
@@ -1154,8 +1197,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     } else if (trig_lds) {
       // <= 4 wavenumbers: the table sits in the four padding floats of this
       // row in each activation buffer (launch_setup), never overwritten
-      trig4[0] = *reinterpret_cast<const float4*>(sm.hA + ln.row * kHS + 32);
-      trig4[1] = *reinterpret_cast<const float4*>(sm.hB + ln.row * kHS + 32);
+      trig4[0] = *reinterpret_cast<const float4*>(sm.hA + ln.row * TW::kHS + TW::kC);
+      trig4[1] = *reinterpret_cast<const float4*>(sm.hB + ln.row * TW::kHS + TW::kC);
       trig4[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     } else {
       const float4* __restrict__ tr =
@@ -1323,8 +1366,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   return r;
 }
 
-template <int kRows, int kWR, bool kWide>
-__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kWide, class TW>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               int block, int batch, Resident& res, bool fast);
 
 // The forcing of this launch can take the harmonic-sum path (else: per-point sinf).
@@ -1369,8 +1412,8 @@ __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln,
 }
 
 // Per-launch setup, part 1: resident registers and the tables in LDS.
-template <int kRows, int kWR, bool kHoist, bool kWide>
-__device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kHoist, bool kWide, class TW>
+__device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               const Lane& ln, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
   const int tid = group_tid<kRows, kWR>();
@@ -1391,7 +1434,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
-  if (!p.fixed) {
+  if (!p.fixed && TW::kDefault) {   // (other towers stream every layer's weights: nothing resident)
     load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
     // loop invariants the specialised one-wave integrators keep resident
@@ -1437,15 +1480,15 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     res.trig[i] = (fast && kHoist && kWR == 64) ? trg[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (fast && p.n_k <= 4 && ln.owner) {
     // ... and into the row padding of the activation buffers
-    *reinterpret_cast<float4*>(sm.hA + ln.row * kHS + 32) = trg[0];
-    *reinterpret_cast<float4*>(sm.hB + ln.row * kHS + 32) = trg[1];
+    *reinterpret_cast<float4*>(sm.hA + ln.row * TW::kHS + TW::kC) = trg[0];
+    *reinterpret_cast<float4*>(sm.hB + ln.row * TW::kHS + TW::kC) = trg[1];
   }
   return fast;
 }
 
 // Per-launch setup of the persistent integrators and the one-group substep kernel.
-template <int kRows, int kWR, bool kHoist, bool kWide>
-__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kHoist, bool kWide, class TW>
+__device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                              const Lane& ln, int batch, Resident& res) {
   const bool fast = setup_weights<kRows, kWR, kHoist>(p, sm, ln, res);
   setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast);
@@ -1498,8 +1541,8 @@ __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int blo
 
 // kReset: also forget the pending harmonic sum and clear Shared::fk (a fresh
 // launch); without it only the parameters the NEXT sums are computed from change.
-template <int kRows, int kWR, bool kReset = true, bool kWide = false>
-__device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide>& sm, Resident& res,
+template <int kRows, int kWR, bool kReset = true, bool kWide = false, class TW = DefaultTower>
+__device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide, TW>& sm, Resident& res,
                                               const SampleSetup& s) {
   constexpr int kThreads = kRows / kWR * 64;
   res.frc_a = s.a; res.frc_omega = s.omega; res.frc_phi = s.phi;
@@ -1515,8 +1558,8 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide>& sm, Res
   }
 }
 
-template <int kRows, int kWR, bool kWide>
-__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide>& sm,
+template <int kRows, int kWR, bool kWide, class TW>
+__device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               int block, int batch, Resident& res,
                                               bool fast) {
   apply_samples<kRows, kWR>(sm, res, fetch_samples<kRows, kWR>(p, block, batch, fast));
@@ -1526,17 +1569,17 @@ __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, 
 // Kernel 1: one fused RK substep (also: plain time derivative, derivative and
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
-template <int kRows, int kWR, int kEq = -1, bool kWide = false>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_kernel(DevParams p,
-                                                                      SubstepArgs a) {
-  __shared__ Shared<kRows, kWR, kWide> sm;
+template <int kRows, int kWR, int kEq = -1, bool kWide = false, class TW = DefaultTower>
+__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void substep_kernel(DevParams p,
+                                                                                SubstepArgs a) {
+  __shared__ Shared<kRows, kWR, kWide, TW> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, false>(p, sm, ln, a.batch, res);
   const float u = ln.valid ? a.y_in[ln.gidx] : 0.0f;   // both half-waves carry the state
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)a.t, threadIdx.x);
   const float f = eval_rhs<kRows, kWR, false, kEq, false>(p, sm, a.batch, u, (float)a.t, (float)a.t, res,
-                                              fast_frc, a.derivs_out, a.coeffs_out, false);
+                                              fast_frc, a.derivs_out, a.coeffs_out, false);   // (kWide, TW: from sm)
   if (!ln.active) return;
   if (a.y_out != nullptr) {
     const float cf = a.c1 * f;
@@ -1734,10 +1777,10 @@ constexpr bool kTraceByDefault = true;
 constexpr bool kTraceByDefault = false;
 #endif
 template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1,
-          bool kTrace = (kEq < 0) && kTraceByDefault, bool kWide = false>
-__global__ __launch_bounds__(kRows / kWR * 64, 2) void integrate_kernel(DevParams p,
-                                                                        IntegrateArgs a) {
-  __shared__ Shared<kRows, kWR, kWide> sm;
+          bool kTrace = (kEq < 0) && kTraceByDefault, bool kWide = false, class TW = DefaultTower>
+__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void integrate_kernel(DevParams p,
+                                                                                  IntegrateArgs a) {
+  __shared__ Shared<kRows, kWR, kWide, TW> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
   const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);

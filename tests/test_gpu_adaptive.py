@@ -338,3 +338,21 @@ def test_start_time_is_not_zero_and_single_sample_batches():
     nfev, status, bad, worst = _check(model, y0, times, batch_forcing(batch, seed0=5),
                                       hip_samples=range(batch))
     assert not bad and (status == 0).all() and worst < TOL
+
+
+@pytest.mark.parametrize('overrides', [dict(kernel_size=7), dict(filter_size=64),
+                                       dict(kernel_size=3)])
+def test_other_towers_adaptive(overrides):
+  """The adaptive integrator on the towers with streamed weights (7 taps, 64
+  filters, 3 taps): per-sample nfev equal to the reference run, both geometries."""
+  for num_points in (64, 96):
+    model = make_model('burgers', True, num_points=num_points, resample_factor=4, **overrides)
+    assert model.kernel_name.startswith('mfma_f32')
+    batch = 6
+    y0 = (0.3 * random_phase_ic(model.equation, batch)).astype(np.float64)
+    forcing = batch_forcing(batch)
+    times = np.linspace(0.0, 0.1, 3)
+    nfev, status, bad, worst = _check(model, y0, times, forcing, hip_samples=(0, 5))
+    print(overrides, num_points, 'nfev', nfev, 'worst {:.1e}'.format(worst))
+    assert not bad, bad
+    assert (status == 0).all()

@@ -251,13 +251,56 @@ def test_smaller_towers_embedded_in_the_mfma_layers(overrides):
 
 
 @pytest.mark.parametrize('overrides', [
-    dict(num_layers=1), dict(filter_size=64), dict(kernel_size=7),
+    dict(kernel_size=7), dict(filter_size=64),
+    dict(kernel_size=6, filter_size=20),                       # embedded in 7 taps x 32
+    dict(filter_size=40, kernel_size=4, num_layers=4, nonlinearity='tanh'),   # in 5 x 64
+    dict(kernel_size=7, model_target='time_derivative'),
+    dict(filter_size=64, model_target='space_derivatives'),
+    dict(kernel_size=3, num_layers=2),                         # the 3-tap tower, no hidden layer
+])
+def test_other_towers_on_mfma(overrides):
+  """training.py:134-136 leaves kernel_size and filter_size free, model.py:455-458
+  builds whatever they say: 7 taps, 64 filters and 3 taps have MFMA towers of
+  their own (rhs_mfma.h Tower<7, 1>, <5, 2>, <3, 1>: weights streamed from L2),
+  nets in between are embedded with zero weights.  One-wave (N = 64) and
+  four-wave (N = 96) groups, all views and 10 midpoint steps against the oracle
+  evaluating the TRUE net; the generic kernel agrees; launch modes agree bit
+  for bit."""
+  for equation, conservative, num_points in (('burgers', True, 64), ('ks', False, 64),
+                                             ('kdv', True, 96)):
+    model = make_model(equation, conservative, num_points=num_points, resample_factor=2,
+                       **overrides)
+    want_kernel = 'mfma_f32_r64' if num_points == 64 else 'mfma_f32_r256'
+    assert model.kernel_name == want_kernel, (overrides, model.kernel_name)
+    batch = 7
+    y0 = random_phase_ic(model.equation, batch)
+    forcing = batch_forcing(batch)
+    model.set_forcing(forcing)
+    mfma_err = _check_all_views(model, y0, 0.2, forcing, None)
+    dt = 1e-5
+    got = model.integrate_fixed(y0, 10, dt=dt, save_every=10).cpu().numpy()
+    want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 10, 10, y0,
+                                  forcing=forcing if equation == 'burgers' else None)
+    assert rel_err(got, want) < TOL, (equation, overrides)
+    per_substep = model.integrate_fixed(y0, 10, dt=dt, save_every=10,
+                                        launch_mode='per_substep').cpu().numpy()
+    np.testing.assert_array_equal(got, per_substep)
+    f64 = model.integrate_fixed(y0, 10, dt=dt, save_every=10, state_dtype='float64').cpu().numpy()
+    assert rel_err(f64, want) < TOL
+    model.set_kernel('generic')
+    generic_err = _check_all_views(model, y0, 0.2, forcing, None)
+    print(equation, num_points, overrides, mfma_err, generic_err)
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=1), dict(filter_size=96), dict(kernel_size=9),
+    dict(kernel_size=7, filter_size=64),
     dict(coefficient_grid_min_size=13), dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
-  """Configurations the MFMA path does not cover (more than 32 filters or 5 taps,
-  one-layer nets, stencils wider than 12) run on the generic kernel (never on
-  the CPU)."""
+  """Configurations the MFMA path does not cover (more than 64 filters or 7 taps, 7
+  taps together with 64 filters, one-layer nets, stencils wider than 12) run on
+  the generic kernel (never on the CPU)."""
   conservative = not overrides.get('ensure_unbiased_coefficients', False)
   model = make_model('burgers', conservative, num_points=64, **overrides)
   if overrides.get('num_layers', 3) != 0:
