@@ -80,7 +80,8 @@ TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.
 
 
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
-                'rk_substep_external', 'stream_fixed', 'differentiator_b1', 'adaptive_rk23',
+                'rk_substep_external', 'stream_fixed', 'stream_fixed_per_step',
+                'differentiator_b1', 'adaptive_rk23',
                 'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024')
 
 
@@ -837,6 +838,14 @@ def extra_configs(args, lib, world):
           'KdV N=64 batch 262144 TILED from 4096 distinct samples, one launch per substep: '
           'the HBM-bound kernel of the path', 262144, unique=4096,
           **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_substep',
+                 steps=200))
+    elif name == 'stream_fixed_per_step':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the same fixed-stencil ensemble (KdV N=64 batch 262144 TILED '
+          'from 4096 distinct samples) with ALL stages of a midpoint step in one launch: the '
+          'stage input stays in the block\'s LDS tile, 8 B per grid point and step',
+          262144, unique=4096,
+          **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_step',
                  steps=200))
     elif name == 'differentiator_b1':
       key, val = _differentiator_config(_variant(args, **base))

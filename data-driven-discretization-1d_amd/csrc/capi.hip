@@ -1580,6 +1580,34 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     if (geo.wave_rows == 64 && launch_mode == DDD_LAUNCH_PER_STEP)
       step_eq = spec_equation(m, geo.rows);
   }
+  if (launch_mode == DDD_LAUNCH_PER_STEP && ddd::stream::supports(m->dp) && !m->explicit_kernel &&
+      !g_debug.no_stream && aligned16(y0) && aligned16(y_out) && (elems % 4) == 0) {
+    // fixed stencils, all stages of a step in one launch of the streaming kernel: the
+    // stage inputs stay in the block's LDS tile, 8 B per grid point and step
+    const long pts = (long)ddd::stream::samples_per_block(m->dp.N) * m->dp.N;
+    const unsigned blocks = (unsigned)(((long)elems + pts - 1) / pts);
+    const float* y = y0;
+    size_t snap = 0;
+    for (int step = 0; step < n_steps; ++step) {
+      const bool saving = (step + 1) % save_every == 0;
+      float* ynew = saving ? y_out + snap * elems : (y == ping ? pong : ping);
+      ddd::StepArgs sa{};
+      sa.t = t0 + (double)step * dt; sa.dt = dt; sa.tab = tab;
+      sa.y_in = y; sa.y_out = ynew; sa.batch = batch;
+      if (ddd::stream::quads_for(m->dp.N) == 2)
+        hipLaunchKernelGGL(ddd::stream::fixed_step_kernel<2>, dim3(blocks),
+                           dim3(ddd::stream::kThreads), 0, stream, m->dp, sa);
+      else
+        hipLaunchKernelGGL(ddd::stream::fixed_step_kernel<1>, dim3(blocks),
+                           dim3(ddd::stream::kThreads), 0, stream, m->dp, sa);
+      y = ynew;
+      if (saving) ++snap;
+    }
+    DDD_HIP(hipGetLastError());
+    m->last_batch = batch;
+    m->last_launch_streamed = true;
+    return DDD_OK;
+  }
   hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
   if (halves > 1) {
     rc = fork_lanes(m, stream, halves);

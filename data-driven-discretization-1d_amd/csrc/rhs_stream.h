@@ -142,5 +142,111 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
   }
 }
 
+// ALL stages of one Runge-Kutta step in one launch (DDD_LAUNCH_PER_STEP): a block
+// already stages whole samples in LDS, so the stage inputs y + a h k are formed in
+// the tile and never leave the CU: 8 B per grid point and STEP (y in, y out)
+// instead of 20 B with one launch per midpoint substep.  Same arithmetic in the
+// same order as the substep chain (y + (a h) k, acc + (b h) k): bit-identical.
+template <int kQuads>
+__global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepArgs a) {
+  constexpr int kPer = 4 * kQuads;
+  constexpr int kTilePoints = kThreads * kPer;
+  constexpr int kWin = kPer + 1 + kGMax - 1;
+  __shared__ float tile[kTilePoints];
+  const int n = p.N;
+  const int pts = samples_per_block(n) * n;
+  const long base = (long)blockIdx.x * pts;
+  const long total = (long)a.batch * n;
+  const long rest = total - base;
+  const int live = rest < (long)pts ? (int)rest : pts;
+  const int i0 = threadIdx.x * kPer;
+  const bool mine = i0 < live;
+  float y[kPer], ynew[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) y[q] = 0.0f;
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(a.y_in + base + i0 + 4 * k);
+      y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w;
+      *reinterpret_cast<float4*>(tile + i0 + 4 * k) = v;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) ynew[q] = y[q];
+  const int s0 = (i0 / n) * n;
+  const int pos0 = i0 - s0;
+  const int gl = p.G >> 1;
+  const int qn = pos0 + kPer >= n ? pos0 + kPer - n : pos0 + kPer;
+  const float h = (float)a.dt;
+  for (int s = 0; s < a.tab.stages; ++s) {
+    __syncthreads();   // the tile holds this stage's input
+    float r[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) r[q] = 0.0f;
+    if (mine) {
+      float w[kWin];
+#pragma unroll
+      for (int j = 0; j < kWin; ++j) {
+        int q = pos0 - gl + j;
+        q = q < 0 ? q + n : q;
+        q = q >= n ? q - n : q;
+        w[j] = tile[s0 + q];
+      }
+      float uc[kPer + 1];
+#pragma unroll
+      for (int k = 0; k < kQuads; ++k) {
+        const float4 v = *reinterpret_cast<const float4*>(tile + i0 + 4 * k);
+        uc[4 * k] = v.x; uc[4 * k + 1] = v.y; uc[4 * k + 2] = v.z; uc[4 * k + 3] = v.w;
+      }
+      uc[kPer] = tile[s0 + qn];
+      float f[kPer + 1];
+#pragma unroll
+      for (int q = 0; q < kPer + 1; ++q) {
+        f[q] = 0.0f;
+        if (q < kPer || p.conservative) {
+          float dv[kMaxDerivs];
+#pragma unroll
+          for (int d = 0; d < kMaxDerivs; ++d) {
+            float acc = 0.0f;
+            if (d < p.D) {
+#pragma unroll
+              for (int g = 0; g < kGMax; ++g) acc = fmaf(p.bias8[d][g], w[q + g], acc);
+            }
+            dv[d] = acc;
+          }
+          f[q] = equation_rhs_or_flux(p.equation, uc[q], dv, p.eta);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < kPer; ++q)
+        r[q] = p.conservative ? -(p.inv_dx * (f[q + 1] - f[q])) : f[q];
+    }
+    const bool last = s + 1 == a.tab.stages;
+    if (a.tab.b[s] != 0.0f || last) {
+      const float c2 = a.tab.b[s] * h;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) ynew[q] = ynew[q] + c2 * r[q];
+    }
+    if (!last) {
+      __syncthreads();   // every stencil read of this stage is done
+      const float c1 = a.tab.a[s + 1] * h;
+      if (mine) {
+#pragma unroll
+        for (int k = 0; k < kQuads; ++k)
+          *reinterpret_cast<float4*>(tile + i0 + 4 * k) =
+              make_float4(y[4 * k] + c1 * r[4 * k], y[4 * k + 1] + c1 * r[4 * k + 1],
+                          y[4 * k + 2] + c1 * r[4 * k + 2], y[4 * k + 3] + c1 * r[4 * k + 3]);
+      }
+    }
+  }
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < kQuads; ++k)
+      *reinterpret_cast<float4*>(a.y_out + base + i0 + 4 * k) =
+          make_float4(ynew[4 * k], ynew[4 * k + 1], ynew[4 * k + 2], ynew[4 * k + 3]);
+  }
+}
+
 }  // namespace stream
 }  // namespace ddd
