@@ -1580,12 +1580,15 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     if (geo.wave_rows == 64 && launch_mode == DDD_LAUNCH_PER_STEP)
       step_eq = spec_equation(m, geo.rows);
   }
-  if (launch_mode == DDD_LAUNCH_PER_STEP && ddd::stream::supports(m->dp) && !m->explicit_kernel &&
-      !g_debug.no_stream && aligned16(y0) && aligned16(y_out) && (elems % 4) == 0) {
+  if (launch_mode == DDD_LAUNCH_PER_STEP && ddd::stream::step_supports(m->dp) &&
+      !m->explicit_kernel && !g_debug.no_stream && aligned16(y0) && aligned16(y_out) &&
+      (elems % 4) == 0) {
     // fixed stencils, all stages of a step in one launch of the streaming kernel: the
-    // stage inputs stay in the block's LDS tile, 8 B per grid point and step
-    const long pts = (long)ddd::stream::samples_per_block(m->dp.N) * m->dp.N;
-    const unsigned blocks = (unsigned)(((long)elems + pts - 1) / pts);
+    // stage inputs stay in the block's LDS tile, 8 B per grid point and step;
+    // persistent blocks (eight per CU) walk over the tiles
+    const long pts = (long)(ddd::stream::kStepTile / m->dp.N) * m->dp.N;
+    const int tiles = (int)(((long)elems + pts - 1) / pts);
+    const int grid = std::min(tiles, 2 * device_simds());
     const float* y = y0;
     size_t snap = 0;
     for (int step = 0; step < n_steps; ++step) {
@@ -1594,12 +1597,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
       ddd::StepArgs sa{};
       sa.t = t0 + (double)step * dt; sa.dt = dt; sa.tab = tab;
       sa.y_in = y; sa.y_out = ynew; sa.batch = batch;
-      if (ddd::stream::quads_for(m->dp.N) == 2)
-        hipLaunchKernelGGL(ddd::stream::fixed_step_kernel<2>, dim3(blocks),
-                           dim3(ddd::stream::kThreads), 0, stream, m->dp, sa);
-      else
-        hipLaunchKernelGGL(ddd::stream::fixed_step_kernel<1>, dim3(blocks),
-                           dim3(ddd::stream::kThreads), 0, stream, m->dp, sa);
+      ddd::stream::launch_fixed_step(dim3(grid), stream, m->dp, sa, tiles);
       y = ynew;
       if (saving) ++snap;
     }

@@ -147,104 +147,162 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
 // the tile and never leave the CU: 8 B per grid point and STEP (y in, y out)
 // instead of 20 B with one launch per midpoint substep.  Same arithmetic in the
 // same order as the substep chain (y + (a h) k, acc + (b h) k): bit-identical.
-template <int kQuads>
-__global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepArgs a) {
-  constexpr int kPer = 4 * kQuads;
-  constexpr int kTilePoints = kThreads * kPer;
-  constexpr int kWin = kPer + 1 + kGMax - 1;
-  __shared__ float tile[kTilePoints];
-  const int n = p.N;
-  const int pts = samples_per_block(n) * n;
-  const long base = (long)blockIdx.x * pts;
-  const long total = (long)a.batch * n;
-  const long rest = total - base;
-  const int live = rest < (long)pts ? (int)rest : pts;
-  const int i0 = threadIdx.x * kPer;
-  const bool mine = i0 < live;
-  float y[kPer], ynew[kPer];
+// Two things keep it a stream although a tile now carries 2-4 stencil passes and
+// barriers between them: (a) blocks are persistent -- a block walks over tiles
+// gridDim.x apart with the NEXT tile's state already requested while the current
+// one is computed; (b) the stencil window is read as aligned 16-byte quads (the
+// thread's 8 points start at a multiple of 8, N % 8 == 0: a quad never straddles the
+// periodic wrap) instead of one dword per window entry.  N % 8 == 0 only.
+constexpr int kStepQuads = 2;                       // float4 rows per thread
+constexpr int kStepPer = 4 * kStepQuads;            // 8 grid points per thread
+constexpr int kStepTile = kThreads * kStepPer;      // 2048 grid points per tile
+inline bool step_supports(const DevParams& p) { return supports(p) && p.N % 8 == 0; }
+
+// Derivative count and form of the equation, as compile-time facts (the kernel is
+// instantiated per equation: with the equation a run-time switch per grid point
+// the fused step was instruction-bound at 2.5 TB/s -- profiles/r4_ablation.txt).
+__host__ __device__ constexpr int eq_derivs(int eq) {
+  return (eq == EQ_KS || eq == EQ_KS_CONS || eq == EQ_BURGERS_GODUNOV || eq == EQ_KDV_GODUNOV) ? 3
+         : eq == EQ_KS_GODUNOV ? 4 : 2;
+}
+__host__ __device__ constexpr bool eq_flux_form(int eq) {
+  return eq == EQ_BURGERS_CONS || eq == EQ_KDV_CONS || eq == EQ_KS_CONS || eq >= EQ_BURGERS_GODUNOV;
+}
+
+// kGl = G / 2: offset of the stencil's first point; window = quads [pos0 - 4, pos0 + 16)
+template <int kEq, int kGl>
+__device__ __forceinline__ void step_stage(const DevParams& p, const float* tile, int s0,
+                                           int pos0, int n, float (&r)[kStepPer]) {
+  static_assert(kGl >= 0 && kGl <= 4, "stencils of up to 8 points");
+  constexpr int kD = eq_derivs(kEq);
+  constexpr bool kFlux = eq_flux_form(kEq);
+  float blk[20];   // tile[s0 + (pos0 - 4 + i) mod N], i = 0 .. 19
 #pragma unroll
-  for (int q = 0; q < kPer; ++q) y[q] = 0.0f;
-  if (mine) {
+  for (int b = 0; b < 5; ++b) {
+    int q = pos0 - 4 + 4 * b;
+    q = q < 0 ? q + n : q;
+    q = q >= n ? q - n : q;
+    const float4 v = *reinterpret_cast<const float4*>(tile + s0 + q);
+    blk[4 * b] = v.x; blk[4 * b + 1] = v.y; blk[4 * b + 2] = v.z; blk[4 * b + 3] = v.w;
+  }
+  float f[kStepPer + 1];
 #pragma unroll
-    for (int k = 0; k < kQuads; ++k) {
-      const float4 v = *reinterpret_cast<const float4*>(a.y_in + base + i0 + 4 * k);
-      y[4 * k] = v.x; y[4 * k + 1] = v.y; y[4 * k + 2] = v.z; y[4 * k + 3] = v.w;
-      *reinterpret_cast<float4*>(tile + i0 + 4 * k) = v;
+  for (int q = 0; q < kStepPer + 1; ++q) {
+    f[q] = 0.0f;
+    if (q < kStepPer || kFlux) {
+      float dv[kMaxDerivs];
+#pragma unroll
+      for (int d = 0; d < kMaxDerivs; ++d) {
+        float acc = 0.0f;
+        if (d < kD) {
+#pragma unroll
+          for (int g = 0; g < kGMax; ++g)   // patches[g] = u[x + g - G/2]; columns >= G are zero
+            if (4 - kGl + q + g < 20) acc = fmaf(p.bias8[d][g], blk[4 - kGl + q + g], acc);
+        }
+        dv[d] = acc;
+      }
+      f[q] = equation_rhs_or_flux(kEq, blk[4 + q], dv, p.eta);
     }
   }
 #pragma unroll
-  for (int q = 0; q < kPer; ++q) ynew[q] = y[q];
+  for (int q = 0; q < kStepPer; ++q)
+    r[q] = kFlux ? -(p.inv_dx * (f[q + 1] - f[q])) : f[q];
+}
+
+template <int kEq, int kGl>
+__global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepArgs a, int tiles) {
+  __shared__ float tile[kStepTile];
+  const int n = p.N;
+  const int pts = (kStepTile / n) * n;                     // whole samples per tile
+  const long total = (long)a.batch * n;
+  const int i0 = threadIdx.x * kStepPer;
   const int s0 = (i0 / n) * n;
   const int pos0 = i0 - s0;
-  const int gl = p.G >> 1;
-  const int qn = pos0 + kPer >= n ? pos0 + kPer - n : pos0 + kPer;
   const float h = (float)a.dt;
-  for (int s = 0; s < a.tab.stages; ++s) {
-    __syncthreads();   // the tile holds this stage's input
-    float r[kPer];
+  const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const auto fetch = [&](int t, float4 (&v)[kStepQuads]) {
+    const long base = (long)t * pts;
+    const long rest = total - base;
+    const int live = rest < (long)pts ? (int)rest : pts;
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) r[q] = 0.0f;
-    if (mine) {
-      float w[kWin];
+    for (int k = 0; k < kStepQuads; ++k)
+      v[k] = (t < tiles && i0 < live)
+                 ? *reinterpret_cast<const float4*>(a.y_in + base + i0 + 4 * k) : zero4;
+  };
+  float4 next[kStepQuads];
+  fetch((int)blockIdx.x, next);
+  for (int t = (int)blockIdx.x; t < tiles; t += (int)gridDim.x) {
+    const long base = (long)t * pts;
+    const long rest = total - base;
+    const int live = rest < (long)pts ? (int)rest : pts;
+    const bool mine = i0 < live;
+    float y[kStepPer], ynew[kStepPer];
 #pragma unroll
-      for (int j = 0; j < kWin; ++j) {
-        int q = pos0 - gl + j;
-        q = q < 0 ? q + n : q;
-        q = q >= n ? q - n : q;
-        w[j] = tile[s0 + q];
-      }
-      float uc[kPer + 1];
-#pragma unroll
-      for (int k = 0; k < kQuads; ++k) {
-        const float4 v = *reinterpret_cast<const float4*>(tile + i0 + 4 * k);
-        uc[4 * k] = v.x; uc[4 * k + 1] = v.y; uc[4 * k + 2] = v.z; uc[4 * k + 3] = v.w;
-      }
-      uc[kPer] = tile[s0 + qn];
-      float f[kPer + 1];
-#pragma unroll
-      for (int q = 0; q < kPer + 1; ++q) {
-        f[q] = 0.0f;
-        if (q < kPer || p.conservative) {
-          float dv[kMaxDerivs];
-#pragma unroll
-          for (int d = 0; d < kMaxDerivs; ++d) {
-            float acc = 0.0f;
-            if (d < p.D) {
-#pragma unroll
-              for (int g = 0; g < kGMax; ++g) acc = fmaf(p.bias8[d][g], w[q + g], acc);
-            }
-            dv[d] = acc;
-          }
-          f[q] = equation_rhs_or_flux(p.equation, uc[q], dv, p.eta);
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < kPer; ++q)
-        r[q] = p.conservative ? -(p.inv_dx * (f[q + 1] - f[q])) : f[q];
+    for (int k = 0; k < kStepQuads; ++k) {
+      y[4 * k] = next[k].x; y[4 * k + 1] = next[k].y; y[4 * k + 2] = next[k].z; y[4 * k + 3] = next[k].w;
     }
-    const bool last = s + 1 == a.tab.stages;
-    if (a.tab.b[s] != 0.0f || last) {
-      const float c2 = a.tab.b[s] * h;
+    __syncthreads();   // the previous tile's last stage has read the LDS tile
 #pragma unroll
-      for (int q = 0; q < kPer; ++q) ynew[q] = ynew[q] + c2 * r[q];
-    }
-    if (!last) {
-      __syncthreads();   // every stencil read of this stage is done
-      const float c1 = a.tab.a[s + 1] * h;
-      if (mine) {
+    for (int k = 0; k < kStepQuads; ++k) *reinterpret_cast<float4*>(tile + i0 + 4 * k) = next[k];
+    fetch(t + (int)gridDim.x, next);   // in flight during this tile's stages
 #pragma unroll
-        for (int k = 0; k < kQuads; ++k)
+    for (int q = 0; q < kStepPer; ++q) ynew[q] = y[q];
+    for (int s = 0; s < a.tab.stages; ++s) {
+      __syncthreads();   // the tile holds this stage's input
+      float r[kStepPer];
+#pragma unroll
+      for (int q = 0; q < kStepPer; ++q) r[q] = 0.0f;
+      if (mine) step_stage<kEq, kGl>(p, tile, s0, pos0, n, r);
+      const bool last = s + 1 == a.tab.stages;
+      if (a.tab.b[s] != 0.0f || last) {
+        const float c2 = a.tab.b[s] * h;
+#pragma unroll
+        for (int q = 0; q < kStepPer; ++q) ynew[q] = ynew[q] + c2 * r[q];
+      }
+      if (!last) {
+        __syncthreads();   // every stencil read of this stage is done
+        const float c1 = a.tab.a[s + 1] * h;
+#pragma unroll
+        for (int k = 0; k < kStepQuads; ++k)
           *reinterpret_cast<float4*>(tile + i0 + 4 * k) =
               make_float4(y[4 * k] + c1 * r[4 * k], y[4 * k + 1] + c1 * r[4 * k + 1],
                           y[4 * k + 2] + c1 * r[4 * k + 2], y[4 * k + 3] + c1 * r[4 * k + 3]);
       }
     }
-  }
-  if (mine) {
+    if (mine) {
 #pragma unroll
-    for (int k = 0; k < kQuads; ++k)
-      *reinterpret_cast<float4*>(a.y_out + base + i0 + 4 * k) =
-          make_float4(ynew[4 * k], ynew[4 * k + 1], ynew[4 * k + 2], ynew[4 * k + 3]);
+      for (int k = 0; k < kStepQuads; ++k)
+        *reinterpret_cast<float4*>(a.y_out + base + i0 + 4 * k) =
+            make_float4(ynew[4 * k], ynew[4 * k + 1], ynew[4 * k + 2], ynew[4 * k + 3]);
+    }
+  }
+}
+
+// Host side: the instantiation for (equation, G / 2).
+template <int kEq>
+inline void launch_fixed_step_eq(int gl, dim3 grid, hipStream_t stream, const DevParams& p,
+                                 const StepArgs& a, int tiles) {
+  switch (gl) {
+    case 0: hipLaunchKernelGGL((fixed_step_kernel<kEq, 0>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+    case 1: hipLaunchKernelGGL((fixed_step_kernel<kEq, 1>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+    case 2: hipLaunchKernelGGL((fixed_step_kernel<kEq, 2>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+    case 3: hipLaunchKernelGGL((fixed_step_kernel<kEq, 3>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+    default: hipLaunchKernelGGL((fixed_step_kernel<kEq, 4>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+  }
+}
+inline void launch_fixed_step(dim3 grid, hipStream_t stream, const DevParams& p, const StepArgs& a,
+                              int tiles) {
+  const int gl = p.G >> 1;
+  switch (p.equation) {
+    case EQ_BURGERS: launch_fixed_step_eq<EQ_BURGERS>(gl, grid, stream, p, a, tiles); break;
+    case EQ_BURGERS_CONS: launch_fixed_step_eq<EQ_BURGERS_CONS>(gl, grid, stream, p, a, tiles); break;
+    case EQ_KDV: launch_fixed_step_eq<EQ_KDV>(gl, grid, stream, p, a, tiles); break;
+    case EQ_KDV_CONS: launch_fixed_step_eq<EQ_KDV_CONS>(gl, grid, stream, p, a, tiles); break;
+    case EQ_KS: launch_fixed_step_eq<EQ_KS>(gl, grid, stream, p, a, tiles); break;
+    case EQ_KS_CONS: launch_fixed_step_eq<EQ_KS_CONS>(gl, grid, stream, p, a, tiles); break;
+    case EQ_BURGERS_GODUNOV: launch_fixed_step_eq<EQ_BURGERS_GODUNOV>(gl, grid, stream, p, a, tiles); break;
+    case EQ_KDV_GODUNOV: launch_fixed_step_eq<EQ_KDV_GODUNOV>(gl, grid, stream, p, a, tiles); break;
+    default: launch_fixed_step_eq<EQ_KS_GODUNOV>(gl, grid, stream, p, a, tiles); break;
   }
 }
 
