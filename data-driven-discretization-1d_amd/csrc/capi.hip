@@ -166,6 +166,7 @@ struct ddd_model {
   bool explicit_kernel = false;      // ddd_set_kernel chose a family (disables automatic variants)
   bool spec_folded = false;          // w_final4 (specialised kernels) holds the folded output layer
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
+  bool last_launch_split = false;    // ... the persistent integrator with two 32-row wavefronts per sample
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
@@ -177,7 +178,9 @@ struct ddd_model {
   float* d_w_hidden = nullptr;
   float* d_w_final4 = nullptr;
   float* d_w_final4_rt = nullptr;
+  float* d_w_final4_split = nullptr;
   bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
+  bool split_auto = true;            // small ensembles: two 32-row wavefronts per sample (kSplit)
   int tower_k = 5, tower_cb = 1;     // conv tower the MFMA kernels carry the net in (rhs_mfma.h Tower)
   bool big() const { return tower_k != ddd::mfma::kKW || tower_cb != 1; }
   float4* d_frc = nullptr;
@@ -564,6 +567,38 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
                   &m->d_w_final4);
       if (rc) return rc;
       m->dp.w_final4 = m->d_w_final4;
+      // the same layer for the split integrators (rhs_mfma.h kSplit): two chunks of
+      // channel groups, each packed on its own and quad-stored in 24 rows
+      {
+        const float* w = m->spec_folded ? wf.data() : w_nat;
+        const float* b = m->spec_folded ? bf.data() : b_nat;
+        const int cout_n = m->spec_folded ? 16 : dp.C_out;
+        const int n_ch = m->spec_folded ? dp.D * dp.G : dp.C_out;
+        const int groups = m->dp.fin4_groups, na = (groups + 1) / 2;
+        const int chunk_rows = ddd::mfma::fin4_regs(2);
+        std::vector<float> both;
+        for (int c = 0; c < 2; ++c) {
+          const int g0 = c == 0 ? 0 : na, ng = c == 0 ? na : groups - na;
+          std::vector<float> chunk((size_t)chunk_rows * 64, 0.0f);
+          for (int k = 0; k < ddd::mfma::kFin4K && ng > 0 && ng <= 2; ++k)
+            for (int gi = 0; gi < ng; ++gi) {
+              const int q = k * ng + gi;
+              for (int r = 0; r < 4; ++r) {
+                const int ch = 4 * (g0 + gi) + r;
+                if (ch >= n_ch || ch >= cout_n) continue;
+                chunk[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
+                    k < 160 ? w[(size_t)k * cout_n + ch] : b[ch];
+              }
+            }
+          const std::vector<float> q4 = quad_rows(chunk.data(), chunk_rows);
+          both.insert(both.end(), q4.begin(), q4.end());
+        }
+        if (groups <= 4) {
+          rc = upload(both, &m->d_w_final4_split);
+          if (rc) return rc;
+          m->dp.w_final4_split = m->d_w_final4_split;
+        }
+      }
     }
   }
   return DDD_OK;
@@ -720,10 +755,14 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   if (m->force_rows == 256 || !fits64) return {256, 64};
   if (m->force_rows == 64) return {64, 64};
   if (m->force_rows == 32 && !m->wide && !m->big()) return {64, 32};   // (no wide / other-tower split)
-  // Measured on MI355X (profiles/r1_ablation.txt): two 32-row wavefronts per
-  // SIMD are slower than one 64-row wavefront even when the batch leaves half
-  // the wave slots empty (B = 1024: 73.6 vs 82.1 TFLOP/s), so the split is
-  // never chosen automatically; it stays selectable for A/B runs.
+  // Round 1 measured two 32-row wavefronts per sample slower than one 64-row wavefront
+  // (output layer issued by both: 73.6 vs 82.1 TFLOP/s at B = 1024).  The per-equation
+  // split integrators (rhs_mfma.h kSplit) divide the output layer's channel groups between
+  // the two wavefronts instead: chosen when the ensemble leaves every SIMD at most ONE
+  // 64-row wavefront (B <= 1024 at N = 64) -- the second wavefront then fills the
+  // exposed latencies of the first (profiles/r4_ablation.txt).
+  // (launch_integrate applies that to the float32 persistent integrator only: the
+  // fused substep and the adaptive kernels have no split form)
   (void)batch;
   return {64, 64};
 }
@@ -795,6 +834,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     return DDD_OK;
   }
   m->last_launch_streamed = false;
+  m->last_launch_split = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
     ddd::DevParams dp = m->dp;
@@ -862,6 +902,7 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   // both geometries, float64 state -- the SciPy-driven reference semantics,
   // integrate.py:154 -- in the one-wave geometry (launch.h)
   int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m, kRows) : -1;
+  if (kWR == 32 && !f64 && m->dp.w_final4_split != nullptr) eq = spec_equation(m, kRows);
   bool traced = false;
 #ifdef DDD_PROBES
   if (a.trace != nullptr) {
@@ -871,8 +912,11 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
     if (!traced) eq = -1;
   }
 #endif
-#define DDD_SPEC_CASE(EQ) \
-  case EQ: ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); return;
+#define DDD_SPEC_CASE(EQ)                                                              \
+  case EQ:                                                                             \
+    if (kWR == 32) ddd::launch::integrate_split_spec<EQ>(m->dp, a, blocks, stream);    \
+    else ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); \
+    return;
   switch (eq) {
     DDD_SPEC_CASE(ddd::EQ_BURGERS)
     DDD_SPEC_CASE(ddd::EQ_BURGERS_CONS)
@@ -912,8 +956,17 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   a.trace = reinterpret_cast<unsigned long long*>(g_debug.trace_ptr);
   a.ablate = g_debug.ablate;
 #endif
+  m->last_launch_split = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
-    const MfmaGeometry geo = mfma_geometry(m, a.batch);
+    MfmaGeometry geo = mfma_geometry(m, a.batch);
+    if (geo.rows == 64 && geo.wave_rows == 64 && std::is_same<ST, float>::value &&
+        m->split_auto && !m->explicit_kernel && m->dp.w_final4_split != nullptr &&
+        spec_equation(m, 64) >= 0) {
+      // small ensembles: two 32-row wavefronts per sample (rhs_mfma.h kSplit)
+      const int spg = 64 / m->dp.N;
+      if ((a.batch + spg - 1) / spg <= device_simds()) geo = {64, 32};
+    }
+    m->last_launch_split = geo.rows == 64 && geo.wave_rows == 32;
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
     else if (geo.rows == 64) launch_mfma_integrate<64, 32, ST>(m, a, stream);
     else launch_mfma_integrate<256, 64, ST>(m, a, stream);
@@ -1349,7 +1402,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_w_final4_split); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   for (auto& slot : m->time_slot) {
@@ -1827,6 +1880,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   a.max_attempts = max_attempts;
   m->last_batch = batch;
   m->last_launch_streamed = false;
+  m->last_launch_split = false;
   if (m->spectral) {
     // float64 right-hand side (SpectralDifferentiator), one workgroup per sample
     const size_t lds = ddd::spectral::lds_bytes(m->sp);
@@ -2053,7 +2107,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
-  return geo.wave_rows == 32 ? "mfma_f32_r64w32" : "mfma_f32_r64";
+  return (geo.wave_rows == 32 || m->last_launch_split) ? "mfma_f32_r64w32" : "mfma_f32_r64";
 }
 
 int64_t ddd_fma_per_point(const ddd_model* m) { return m ? m->fma_per_point : 0; }

@@ -73,6 +73,10 @@ struct DevParams {
   const float* w_hidden;   // hidden layers, (L-2) x 81 rows (each layer padded to 84)
   // output layer packed for the 4x4x1 broadcast MFMA (rhs_mfma.h: final_layer4), 41 rows:
   const float* w_final4;      // live channels renumbered contiguously, ceil(channels / 4) groups
+  // the same layer for the split integrators (two 32-row wavefronts per sample, rhs_mfma.h
+  // kSplit): chunk 0 = groups [0, ceil(NG / 2)), chunk 1 = the rest, each packed on its own
+  // (q = k * groups_of_chunk + g) in 24 quad-stored rows; null: no split kernels for this model
+  const float* w_final4_split;
   // run-time-parameterised kernels: the live channel groups packed two by two
   // (pair gp: fin4_regs(2) rows for groups 2 gp, 2 gp + 1; an odd last group:
   // fin4_regs(1) rows), channels in natural / G d + g (folded) numbering; plain [rows][64]

@@ -21,6 +21,10 @@ namespace launch {
 template <int kEq>
 void integrate_spec(int rows, bool f64, bool traced, const DevParams& p, const IntegrateArgs& a,
                     int blocks, hipStream_t stream);
+// one sample on two 32-row wavefronts, output layer split by channel groups (float32 state)
+template <int kEq>
+void integrate_split_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
+                          hipStream_t stream);
 // grid: workgroups to launch (<= groups); every workgroup walks over groups.
 template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
@@ -42,7 +46,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
                                     hipStream_t);                                              \
   template <> void adaptive_spec<EQ>(int, const DevParams&, const AdaptiveArgs&, int,          \
                                      hipStream_t);                                             \
-  template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t);
+  template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
+  template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t);
 DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
 DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
 #undef DDD_DECLARE_SPEC

@@ -40,6 +40,13 @@ void integrate_spec<DDD_EQ>(int rows, bool f64, bool traced, const DevParams& p,
 }
 
 template <>
+void integrate_split_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int blocks,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::integrate_kernel<64, 32, float, true, DDD_EQ>), dim3(blocks), dim3(128),
+                     0, stream, p, a);
+}
+
+template <>
 void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, int groups,
                           int grid, hipStream_t stream) {
   if (rows == 64)

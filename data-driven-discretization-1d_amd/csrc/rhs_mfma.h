@@ -951,7 +951,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // LDS offsets / permute addresses / patch indices in registers (kKeepOffsets);
   // the per-equation ones also the output layer's weights and the grid point's
   // cos / sin table (kKeepRows)
-  constexpr bool kKeepOffsets = kWR == 64 && kHoist;
+  // kSplit (per-equation integrators, <64, 32>): ONE sample on TWO 32-row wavefronts
+  // for ensembles that leave SIMDs with a single 64-row wavefront -- each wavefront
+  // carries one 32-row tile through the input and hidden layers (half the MFMAs
+  // each); the output layer, whose 4x4x1 form covers 64 rows per instruction, is
+  // split by CHANNEL GROUPS instead of duplicated: wavefront 0 issues groups
+  // [0, ceil(NG / 2)) for all 64 rows, wavefront 1 the rest, and the channels meet
+  // in the free activation buffer.  Every accumulation chain keeps its order: the
+  // bits equal the one-wavefront kernel's.
+  constexpr bool kSplit = kSpec && kRows == 64 && kWR == 32 && kHoist;
+  constexpr bool kKeepOffsets = (kWR == 64 || kSplit) && kHoist;
   constexpr bool kKeepRows = kKeepOffsets && kEq >= 0 && !kLean;
   constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
   const int tid = opaque(group_tid<kRows, kWR>());
@@ -1046,6 +1055,44 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // output layer: weights resident (specialised one-wave integrators) or
       // fetched from L2 here, in flight across the forcing sums below
       // (run-time kernels: the first chunk, up to three groups)
+      if constexpr (kSplit) {
+        constexpr int kNA = (kNG + 1) / 2, kNB = kNG - kNA;   // channel groups of wavefront 0 / 1
+        constexpr bool kMaskedSums = spec_folded(kSpec ? kEq : 0);
+        if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
+        group_barrier<kRows, kWR>();   // both tiles of the last hidden layer are in LDS
+        int off4[kKW];
+#pragma unroll
+        for (int k = 0; k < kKW; ++k) off4[k] = res.fin4_off[k];   // rows of lane == row (0 .. 63)
+        float* xch = out + ln.lane * kHS;   // this row's channels, in the free buffer
+        if (ln.wave == 0) {   // wave-uniform
+          float wa[fin4_regs(kNA)];
+#pragma unroll
+          for (int s2 = 0; s2 < fin4_regs(kNA); ++s2) wa[s2] = res.w_fin4[s2];
+          f32x4 acc[kNA];
+          final_layer4<kNA>(in, wa, off4, acc);
+#pragma unroll
+          for (int g4 = 0; g4 < kNA; ++g4)
+            *reinterpret_cast<float4*>(xch + 4 * g4) =
+                make_float4(acc[g4][0], acc[g4][1], acc[g4][2], acc[g4][3]);
+        } else if constexpr (kNB > 0) {
+          float wb[fin4_regs(kNB)];
+#pragma unroll
+          for (int s2 = 0; s2 < fin4_regs(kNB); ++s2) wb[s2] = res.w_fin4[s2];
+          f32x4 acc[kNB];
+          final_layer4<kNB>(in, wb, off4, acc);
+#pragma unroll
+          for (int g4 = 0; g4 < kNB; ++g4)
+            *reinterpret_cast<float4*>(xch + 4 * (kNA + g4)) =
+                make_float4(acc[g4][0], acc[g4][1], acc[g4][2], acc[g4][3]);
+        }
+        group_barrier<kRows, kWR>();
+        const float* mine = out + ln.row * kHS;   // the VALU phases' row of this lane
+#pragma unroll
+        for (int g4 = 0; g4 < kNG; ++g4) {
+          const float4 v = *reinterpret_cast<const float4*>(mine + 4 * g4);
+          net[4 * g4] = v.x; net[4 * g4 + 1] = v.y; net[4 * g4 + 2] = v.z; net[4 * g4 + 3] = v.w;
+        }
+      } else {
       constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs_t<TW>(3);
       float wf4[kFirstRows];
       if (!kKeepRows) {
@@ -1171,6 +1218,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
           }
         }
       }
+      }   // !kSplit
       DDD_STAMP(3);
     }
   } else {
@@ -1385,7 +1433,8 @@ __device__ __forceinline__ bool forcing_is_fast(const DevParams& p) {
 template <int kRows, int kWR>
 __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln, Resident& res) {
   int rows[kKW];
-  tap_rows<kRows == 64>(ln, ln.row, p.N, rows);
+  // (two 32-row wavefronts per sample: the output layer runs lane == row over all 64 rows)
+  tap_rows<kRows == 64>(ln, kWR == 32 ? ln.lane : ln.row, p.N, rows);
 #pragma unroll
   for (int k = 0; k < kKW; ++k)   // opaque: keep it in a register, do not recompute
     res.fin4_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)));
@@ -1443,6 +1492,15 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
       if (p.w_final4 != nullptr)   // (dead in the run-time kernels, null for wide models)
         load_rows4<fin4_regs(4)>(p.w_final4, ln.lane, res.w_fin4);   // (zero padded to 4 groups)
     }
+    if (kHoist && kWR == 32 && p.w_final4_split != nullptr) {
+      // split integrators: this wavefront's chunk of channel groups (two chunks of
+      // padded_rows4(fin4_regs(2)) rows each; dead code in the run-time kernels)
+      float chunk[fin4_regs(2)];
+      load_rows4<fin4_regs(2)>(p.w_final4_split + (size_t)ln.wave * padded_rows4(fin4_regs(2)) * 64,
+                               ln.lane, chunk);
+#pragma unroll
+      for (int s2 = 0; s2 < fin4_regs(2); ++s2) res.w_fin4[s2] = chunk[s2];
+    }
   }
   // cos / sin of this grid point's spatial phases (requested LAST: the register
   // allocator copies one of these values right after the load, and that wait
@@ -1461,7 +1519,8 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     res.frc_slot = (fast && tid < spg * p.n_k * 2)
                        ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
   }
-  if (!p.fixed && kHoist && kWR == 64) lane_offsets<kRows, kWR>(p, ln, res);
+  if (!p.fixed && kHoist && (kWR == 64 || p.w_final4_split != nullptr))
+    lane_offsets<kRows, kWR>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
     sm.pm[i] = make_float2(0.0f, 0.0f);
@@ -1477,7 +1536,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
 #pragma unroll
   for (int i = 0; i < kTrigMax / 4; ++i)
-    res.trig[i] = (fast && kHoist && kWR == 64) ? trg[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    res.trig[i] = (fast && kHoist) ? trg[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (fast && p.n_k <= 4 && ln.owner) {
     // ... and into the row padding of the activation buffers
     *reinterpret_cast<float4*>(sm.hA + ln.row * TW::kHS + TW::kC) = trg[0];

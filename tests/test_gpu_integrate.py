@@ -265,6 +265,38 @@ def test_fixed_stencil_streaming_kernels_agree(cls_name, n):
       assert rel_err(b[:, :3], want) < TOL, (scheme, cls_name)
 
 
+@pytest.mark.parametrize('equation,conservative,num_points', [
+    ('burgers', True, 64), ('burgers', False, 32), ('kdv', True, 64), ('ks', False, 16)])
+def test_small_ensembles_run_two_wavefronts_per_sample(equation, conservative, num_points):
+  """Ensembles that leave every SIMD at most one 64-row wavefront (B <= 1024 at N = 64) run
+  the per-equation integrators with each 64-row group on TWO 32-row wavefronts, the output
+  layer's channel groups divided between them (rhs_mfma.h kSplit).  Every accumulation chain
+  keeps its order, so a sample's bits do not depend on the ensemble around it: equal to
+  the one-wavefront kernel (large ensemble, and the forced mfma64 geometry) and to one
+  launch per substep."""
+  model = make_model(equation, conservative, num_points=num_points, resample_factor=2)
+  big, small = 1500 * (64 // num_points), 37
+  forcing = batch_forcing(big) if equation == 'burgers' else None
+  y0 = random_phase_ic(model.equation, big)
+  dt = model.equation.time_step
+  if forcing is not None:
+    model.set_forcing(forcing)
+  a = model.integrate_fixed(y0, 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64'
+  if forcing is not None:
+    model.set_forcing({k: v[:small] for k, v in forcing.items()})
+  b = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64w32'
+  np.testing.assert_array_equal(a[:, :small], b)
+  c = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6,
+                            launch_mode='per_substep').cpu().numpy()
+  np.testing.assert_array_equal(b, c)
+  model.set_kernel('mfma64')
+  d = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64'
+  np.testing.assert_array_equal(b, d)
+
+
 def test_float64_state():
   model = make_model('burgers', False, num_points=64)
   forcing = batch_forcing(4)
