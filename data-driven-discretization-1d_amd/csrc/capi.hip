@@ -963,8 +963,11 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
         m->split_auto && !m->explicit_kernel && m->dp.w_final4_split != nullptr &&
         spec_equation(m, 64) >= 0) {
       // small ensembles: two 32-row wavefronts per sample (rhs_mfma.h kSplit)
+      // measured (profiles/r4_ablation.txt, N = 64): B = 256: 1.63 x the one-wavefront kernel (twice
+      // the SIMDs busy), B = 512: 0.97 x, B = 1024: 0.89 x (two coupled wavefronts per SIMD lose to one
+      // free-running one) -- so only below three eighths of a wavefront per SIMD
       const int spg = 64 / m->dp.N;
-      if ((a.batch + spg - 1) / spg <= device_simds()) geo = {64, 32};
+      if (8 * ((a.batch + spg - 1) / spg) <= 3 * device_simds()) geo = {64, 32};
     }
     m->last_launch_split = geo.rows == 64 && geo.wave_rows == 32;
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);

@@ -297,16 +297,16 @@ def test_attempt_limit_and_argument_checks():
   assert np.array_equal(y[0].cpu().numpy(), y0) and (nfev.cpu().numpy() == 1).all()
 
 def test_generic_kernel_models():
-  """Nets the MFMA path does not carry (here kernel_size = 7, filter_size = 64) and the WENO5
+  """Nets the MFMA path does not carry (here kernel_size = 9, filter_size = 96) and the WENO5
   exact Burgers right-hand side: one workgroup + one controller per sample on the
   generic kernel, against the reference run and against SciPy over the same
   kernel."""
-  model = make_model('kdv', True, num_points=64, resample_factor=4, kernel_size=7)
+  model = make_model('kdv', True, num_points=64, resample_factor=4, kernel_size=9)
   assert model.kernel_name == 'generic'
   y0 = random_phase_ic(model.equation, 5).astype(np.float64)
   nfev, status, bad, worst = _check(model, y0, np.linspace(0, 0.1, 3), hip_samples=(0, 4))
   assert not bad and (status == 0).all()
-  forced = make_model('burgers', False, num_points=48, resample_factor=2, filter_size=64)
+  forced = make_model('burgers', False, num_points=48, resample_factor=2, filter_size=96)
   assert forced.kernel_name == 'generic'
   y0 = (0.4 * random_phase_ic(forced.equation, 4)).astype(np.float64)
   nfev, status, bad, worst = _check(forced, y0, np.array([0.0, 0.07, 0.2]), batch_forcing(4),
