@@ -82,7 +82,8 @@ TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
                 'rk_substep_external', 'stream_fixed', 'stream_fixed_per_step',
                 'differentiator_b1', 'adaptive_rk23',
-                'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024')
+                'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024',
+                'tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096', 'burgers_b256')
 
 
 def parse_args(argv=None):
@@ -847,6 +848,20 @@ def extra_configs(args, lib, world):
           262144, unique=4096,
           **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_step',
                  steps=200))
+    elif name in ('tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096'):
+      hp = {'tower_k7_b4096': {'kernel_size': 7}, 'tower_f64_b4096': {'filter_size': 64},
+            'tower_k3_b4096': {'kernel_size': 3}}[name]
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the headline workload with hyper-parameters {} '
+          '(training.py:134-136 leaves them free): the MFMA towers with streamed weights; '
+          'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
+          **dict(base, hparams=json.dumps(hp), steps=200))
+    elif name == 'burgers_b256':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
+          'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '
+          'wavefronts, output layer split by channel groups', 256,
+          **dict(base, steps=1000))
     elif name == 'differentiator_b1':
       key, val = _differentiator_config(_variant(args, **base))
     elif name == 'adaptive_rk23':
