@@ -76,7 +76,8 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
 MEASURED_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md: float4 copy, the achievable HBM rate
-TRAFFIC_TABLES = ('r3_hbm_traffic.json', 'r2_hbm_traffic.json', 'r1_hbm_traffic.json')   # newest first
+TRAFFIC_TABLES = ('r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json',
+                  'r1_hbm_traffic.json')   # newest first
 
 
 CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burgers_per_step',
@@ -490,7 +491,7 @@ def summarize(args, eq, model, m, world, n, batch, stages):
   compute_bound = not args.baseline_stencils
   traffic, traffic_source, traffic_command = measured_traffic(
       type(eq).__name__, n, batch, args.launch_mode, args.baseline_stencils,
-      state_dtype=args.state_dtype)
+      state_dtype=args.state_dtype, hparams=json.loads(getattr(args, 'hparams', '{}') or '{}'))
   roofline = {
       'bound': 'mfma' if compute_bound else 'hbm',
       'achieved': achieved_tflops if compute_bound else achieved_gbps,
@@ -1029,7 +1030,8 @@ def main():
     dist.destroy_process_group()
 
 
-def measured_traffic(equation, num_points, batch, launch_mode, fixed, state_dtype='float32'):
+def measured_traffic(equation, num_points, batch, launch_mode, fixed, state_dtype='float32',
+                     hparams=None):
   """(HBM bytes per launch of the dominant kernel, source file) from the
   committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in separate
   runs, gfx950 correction applied; profiles/r*_hbm_traffic.json), or
@@ -1042,6 +1044,8 @@ def measured_traffic(equation, num_points, batch, launch_mode, fixed, state_dtyp
               launch_mode=launch_mode, fixed=bool(fixed))
   if state_dtype != 'float32':
     want['state_dtype'] = state_dtype
+  if hparams:
+    want['hparams'] = hparams   # (another net: another kernel, other weight traffic)
   for name in TRAFFIC_TABLES:
     path = os.path.join(ROOT, 'profiles', name)
     try:
