@@ -150,13 +150,20 @@ __global__ __launch_bounds__(kThreads) void fixed_substep_kernel(DevParams p, Su
 // Two things keep it a stream although a tile now carries 2-4 stencil passes and
 // barriers between them: (a) blocks are persistent -- a block walks over tiles
 // gridDim.x apart with the NEXT tile's state already requested while the current
-// one is computed; (b) the stencil window is read as aligned 16-byte quads (the
-// thread's 8 points start at a multiple of 8, N % 8 == 0: a quad never straddles the
-// periodic wrap) instead of one dword per window entry.  N % 8 == 0 only.
-constexpr int kStepQuads = 2;                       // float4 rows per thread
-constexpr int kStepPer = 4 * kStepQuads;            // 8 grid points per thread
-constexpr int kStepTile = kThreads * kStepPer;      // 2048 grid points per tile
-inline bool step_supports(const DevParams& p) { return supports(p) && p.N % 8 == 0; }
+// one is computed; (b) the stencil window is read as aligned 16-byte quads (a
+// thread's points start at a multiple of four, N % 4 == 0: a quad never straddles the
+// periodic wrap) instead of one dword per window entry; (c) four points per thread:
+// small threads, many wavefronts -- the kernel is latency-bound between barriers.
+#ifndef DDD_STEP_QUADS
+#define DDD_STEP_QUADS 1   // measured: 1 -> 6.50e11, 2 -> 4.31e11, 4 -> 3.48e11 grid-point-steps/s (occupancy:
+#endif                     // the kernel is latency-bound between its barriers, profiles/r4_ablation.txt)
+constexpr int kStepQuads = DDD_STEP_QUADS;          // float4 rows per thread
+constexpr int kStepPer = 4 * kStepQuads;            // grid points per thread
+constexpr int kStepTile = kThreads * kStepPer;      // grid points per tile
+constexpr int kStepWin = kStepPer + 12;             // window floats: quads [pos0 - 4, pos0 + kStepPer + 8)
+inline bool step_supports(const DevParams& p) {
+  return supports(p) && p.N % kStepPer == 0 && p.G >= 3;
+}
 
 // Derivative count and form of the equation, as compile-time facts (the kernel is
 // instantiated per equation: with the equation a run-time switch per grid point
@@ -169,16 +176,18 @@ __host__ __device__ constexpr bool eq_flux_form(int eq) {
   return eq == EQ_BURGERS_CONS || eq == EQ_KDV_CONS || eq == EQ_KS_CONS || eq >= EQ_BURGERS_GODUNOV;
 }
 
-// kGl = G / 2: offset of the stencil's first point; window = quads [pos0 - 4, pos0 + 16)
-template <int kEq, int kGl>
+// kG: stencil points (no FMAs on zero-padded columns); G / 2 = offset of the stencil's first
+// point; window = quads [pos0 - 4, pos0 + 16)
+template <int kEq, int kG>
 __device__ __forceinline__ void step_stage(const DevParams& p, const float* tile, int s0,
                                            int pos0, int n, float (&r)[kStepPer]) {
-  static_assert(kGl >= 0 && kGl <= 4, "stencils of up to 8 points");
+  static_assert(kG >= 3 && kG <= kGMax, "stencils of 3 to 8 points");
+  constexpr int kGl = kG / 2;
   constexpr int kD = eq_derivs(kEq);
   constexpr bool kFlux = eq_flux_form(kEq);
-  float blk[20];   // tile[s0 + (pos0 - 4 + i) mod N], i = 0 .. 19
+  float blk[kStepWin];   // tile[s0 + (pos0 - 4 + i) mod N]
 #pragma unroll
-  for (int b = 0; b < 5; ++b) {
+  for (int b = 0; b < kStepWin / 4; ++b) {
     int q = pos0 - 4 + 4 * b;
     q = q < 0 ? q + n : q;
     q = q >= n ? q - n : q;
@@ -196,8 +205,8 @@ __device__ __forceinline__ void step_stage(const DevParams& p, const float* tile
         float acc = 0.0f;
         if (d < kD) {
 #pragma unroll
-          for (int g = 0; g < kGMax; ++g)   // patches[g] = u[x + g - G/2]; columns >= G are zero
-            if (4 - kGl + q + g < 20) acc = fmaf(p.bias8[d][g], blk[4 - kGl + q + g], acc);
+          for (int g = 0; g < kG; ++g)   // patches[g] = u[x + g - G/2]
+            acc = fmaf(p.bias8[d][g], blk[4 - kGl + q + g], acc);
         }
         dv[d] = acc;
       }
@@ -209,7 +218,7 @@ __device__ __forceinline__ void step_stage(const DevParams& p, const float* tile
     r[q] = kFlux ? -(p.inv_dx * (f[q + 1] - f[q])) : f[q];
 }
 
-template <int kEq, int kGl>
+template <int kEq, int kG>
 __global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepArgs a, int tiles) {
   __shared__ float tile[kStepTile];
   const int n = p.N;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepA
       float r[kStepPer];
 #pragma unroll
       for (int q = 0; q < kStepPer; ++q) r[q] = 0.0f;
-      if (mine) step_stage<kEq, kGl>(p, tile, s0, pos0, n, r);
+      if (mine) step_stage<kEq, kG>(p, tile, s0, pos0, n, r);
       const bool last = s + 1 == a.tab.stages;
       if (a.tab.b[s] != 0.0f || last) {
         const float c2 = a.tab.b[s] * h;
@@ -278,21 +287,21 @@ __global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepA
   }
 }
 
-// Host side: the instantiation for (equation, G / 2).
+// Host side: the instantiation for (equation, stencil width).
 template <int kEq>
-inline void launch_fixed_step_eq(int gl, dim3 grid, hipStream_t stream, const DevParams& p,
+inline void launch_fixed_step_eq(int g, dim3 grid, hipStream_t stream, const DevParams& p,
                                  const StepArgs& a, int tiles) {
-  switch (gl) {
-    case 0: hipLaunchKernelGGL((fixed_step_kernel<kEq, 0>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
-    case 1: hipLaunchKernelGGL((fixed_step_kernel<kEq, 1>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
-    case 2: hipLaunchKernelGGL((fixed_step_kernel<kEq, 2>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
-    case 3: hipLaunchKernelGGL((fixed_step_kernel<kEq, 3>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
-    default: hipLaunchKernelGGL((fixed_step_kernel<kEq, 4>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+#define DDD_STEP_G(G) \
+  case G: hipLaunchKernelGGL((fixed_step_kernel<kEq, G>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
+  switch (g) {
+    DDD_STEP_G(3) DDD_STEP_G(4) DDD_STEP_G(5) DDD_STEP_G(6) DDD_STEP_G(7)
+    default: hipLaunchKernelGGL((fixed_step_kernel<kEq, 8>), grid, dim3(kThreads), 0, stream, p, a, tiles); break;
   }
+#undef DDD_STEP_G
 }
 inline void launch_fixed_step(dim3 grid, hipStream_t stream, const DevParams& p, const StepArgs& a,
                               int tiles) {
-  const int gl = p.G >> 1;
+  const int gl = p.G;   // (step_supports: 3 <= G <= 8)
   switch (p.equation) {
     case EQ_BURGERS: launch_fixed_step_eq<EQ_BURGERS>(gl, grid, stream, p, a, tiles); break;
     case EQ_BURGERS_CONS: launch_fixed_step_eq<EQ_BURGERS_CONS>(gl, grid, stream, p, a, tiles); break;
