@@ -108,8 +108,8 @@ template <int kRows>
 constexpr bool adaptive_lean() { return ((kRows == 64 ? 1 : 2) & DDD_ADAPTIVE_LEAN) != 0; }
 
 template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false, class TW = DefaultTower>
-__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void adaptive_kernel(DevParams p,
-                                                                                 AdaptiveArgs a) {
+__global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) void adaptive_kernel(
+    DevParams p, AdaptiveArgs a) {
   __shared__ Shared<kRows, kWR, kWide, TW> sm;
   __shared__ AdaptiveShared<kRows> as;
   static_assert(kRows == kWR || kWide || !TW::kDefault ||

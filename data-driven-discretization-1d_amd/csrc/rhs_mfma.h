@@ -94,8 +94,16 @@ template <int kRows, int kWR = 64, bool kWide = false, class TW = DefaultTower>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
   static constexpr int kFkMax = 3 * kRows / 4;  // samples * 12 harmonic sums (zero padded)
+  // One-wave groups of the 64-channel towers keep ONE activation buffer: a wavefront issues
+  // every operand read of a layer before it stores the layer's output (LDS operations of one
+  // wavefront execute in order), so the layer can be written in place -- 20 KB instead of
+  // 37 KB per group: eight groups per CU = two wavefronts per SIMD instead of one.  hB then
+  // only holds the second half of the per-row cos / sin table (four floats per row).
+  static constexpr bool kSingleBuffer = kRows == kWR && TW::kCB == 2;
+  static constexpr int kHBStride = kSingleBuffer ? 4 : TW::kHS;
+  static constexpr int kHBPad = kSingleBuffer ? 0 : TW::kC;      // float offset of a row's padding in hB
   float hA[kRows * TW::kHS];
-  float hB[kRows * TW::kHS];
+  float hB[kRows * kHBStride];
   float u[kRows];
   float un[kRows == kWR ? 1 : kRows];   // u / standard_deviation (input-layer operand; one-wave
                                         // groups feed the input layer by lane permutes)
@@ -111,9 +119,9 @@ static_assert(8 * sizeof(Shared<64>) <= 158 * 1024, "2 x four-group workgroups p
 static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
 static_assert(sizeof(Shared<64, 64, true>) <= 22 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
               "wide flavour: 7 x 64-row / 2 x 256-row workgroups per CU");
-static_assert(sizeof(Shared<64, 64, false, Tower<7, 2>>) <= 40 * 1024 &&
-              sizeof(Shared<256, 64, false, Tower<7, 2>>) <= 160 * 1024,
-              "64-filter towers: 4 x 64-row / 1 x 256-row workgroups per CU");
+static_assert(sizeof(Shared<64, 64, false, Tower<5, 2>>) <= 20 * 1024 &&
+              sizeof(Shared<256, 64, false, Tower<5, 2>>) <= 160 * 1024,
+              "64-filter towers: 8 x 64-row (single activation buffer) / 1 x 256-row workgroups per CU");
 
 // A one-wave row group (kRows == kWR) may be one of several INDEPENDENT groups
 // sharing a workgroup (substep_quad_kernel): its thread index is the lane, and
@@ -622,7 +630,7 @@ struct StreamState {
   float4 bbuf[2][kT];
   int rowo[kT][TW::kK];              // LDS byte offsets of the operand rows (+ 64 half)
   const float4* __restrict__ wq;     // this lane's weight stream
-  const char* __restrict__ in;
+  const char* in;
 };
 
 // operand group g: tap g / (4 kCB), input block (g / 4) % kCB, quad g % 4
@@ -676,9 +684,8 @@ __device__ __forceinline__ void stream_groups(StreamState<TW, kT>& st,
 
 template <class TW, int kWR>
 __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const Lane& ln,
-                                                    int hidden_index,
-                                                    const float* __restrict__ in,
-                                                    float* __restrict__ out,
+                                                    int hidden_index, const float* in,
+                                                    float* out,   // (may be `in`: see Shared::kSingleBuffer)
                                                     const int (&rows)[2][TW::kK], int act) {
   constexpr int kT = kWR / 32, kCB = TW::kCB, kG = TW::kHidGroups;
   const int j = ln.lane & 31, half = ln.lane >> 5;
@@ -804,6 +811,11 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
   fin4_mfmas<NG, (TW::kFinK - 1) * NG>(w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc,
                                        std::make_integer_sequence<int, NG>{});
 }
+
+// Wavefronts per SIMD the kernels are compiled for: two, except the four-wave groups of the
+// 64-channel towers (158 KB of LDS: one workgroup per CU anyway).
+template <int kRows, int kWR, class TW>
+constexpr int min_waves() { return (TW::kCB == 2 && kRows != kWR) ? 1 : 2; }
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
 struct Resident {
@@ -1038,7 +1050,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
     float* in = sm.hA;
-    float* out = sm.hB;
+    float* out = Shared<kRows, kWR, kWide, TW>::kSingleBuffer ? sm.hA : sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
       if constexpr (!TW::kDefault) {
         group_barrier<kRows, kWR>();
@@ -1246,7 +1258,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // <= 4 wavenumbers: the table sits in the four padding floats of this
       // row in each activation buffer (launch_setup), never overwritten
       trig4[0] = *reinterpret_cast<const float4*>(sm.hA + ln.row * TW::kHS + TW::kC);
-      trig4[1] = *reinterpret_cast<const float4*>(sm.hB + ln.row * TW::kHS + TW::kC);
+      trig4[1] = *reinterpret_cast<const float4*>(
+          sm.hB + ln.row * Shared<kRows, kWR, kWide, TW>::kHBStride + Shared<kRows, kWR, kWide, TW>::kHBPad);
       trig4[2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     } else {
       const float4* __restrict__ tr =
@@ -1540,7 +1553,8 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   if (fast && p.n_k <= 4 && ln.owner) {
     // ... and into the row padding of the activation buffers
     *reinterpret_cast<float4*>(sm.hA + ln.row * TW::kHS + TW::kC) = trg[0];
-    *reinterpret_cast<float4*>(sm.hB + ln.row * TW::kHS + TW::kC) = trg[1];
+    *reinterpret_cast<float4*>(sm.hB + ln.row * Shared<kRows, kWR, kWide, TW>::kHBStride +
+                               Shared<kRows, kWR, kWide, TW>::kHBPad) = trg[1];
   }
   return fast;
 }
@@ -1629,8 +1643,8 @@ __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, 
 // coefficient views).  State crosses HBM once in and once out.
 // ---------------------------------------------------------------------------
 template <int kRows, int kWR, int kEq = -1, bool kWide = false, class TW = DefaultTower>
-__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void substep_kernel(DevParams p,
-                                                                                SubstepArgs a) {
+__global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) void substep_kernel(
+    DevParams p, SubstepArgs a) {
   __shared__ Shared<kRows, kWR, kWide, TW> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, threadIdx.x, blockIdx.x);
   Resident res;
@@ -1837,8 +1851,8 @@ constexpr bool kTraceByDefault = false;
 #endif
 template <int kRows, int kWR, typename ST, bool kHoist, int kEq = -1,
           bool kTrace = (kEq < 0) && kTraceByDefault, bool kWide = false, class TW = DefaultTower>
-__global__ __launch_bounds__(kRows / kWR * 64, 3 - TW::kCB) void integrate_kernel(DevParams p,
-                                                                                  IntegrateArgs a) {
+__global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) void integrate_kernel(
+    DevParams p, IntegrateArgs a) {
   __shared__ Shared<kRows, kWR, kWide, TW> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
