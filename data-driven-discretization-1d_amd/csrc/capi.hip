@@ -1828,6 +1828,8 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   if (rc) return rc;
   if (times == nullptr || n_times < 1)
     return fail(DDD_ERR_INVALID_ARGUMENT, "times must hold at least one value");
+  if (n_times >= (1 << 28))   // (the packed per-sample controllers keep the output index in 28 bits)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "n_times = %d: at most 2^28 - 1 output times", n_times);
   for (int i = 0; i < n_times; ++i)
     if (!std::isfinite(times[i]) || (i > 0 && !(times[i] > times[i - 1])))
       return fail(DDD_ERR_INVALID_ARGUMENT, "times must be finite and strictly increasing");
