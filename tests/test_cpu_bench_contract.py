@@ -28,7 +28,8 @@ def test_measured_traffic_lookup():
   for entry in newest['entries']:
     m = entry['match']
     got, source, _ = bench.measured_traffic(m['equation'], m['num_points'],
-                                            m['batch_per_gpu'], m['launch_mode'], m['fixed'])
+                                            m['batch_per_gpu'], m['launch_mode'], m['fixed'],
+                                            hparams=m.get('hparams'))   # (other nets: own entries)
     assert got == entry['traffic_bytes_per_launch'] and source.startswith('profiles/')
     # FETCH_SIZE (with the gfx950 correction) + WRITE_SIZE, in bytes
     want = 1024 * (entry['fetch_correction'] * entry['fetch_size_kb'] + entry['write_size_kb'])
