@@ -755,14 +755,9 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   if (m->force_rows == 256 || !fits64) return {256, 64};
   if (m->force_rows == 64) return {64, 64};
   if (m->force_rows == 32 && !m->wide && !m->big()) return {64, 32};   // (no wide / other-tower split)
-  // Round 1 measured two 32-row wavefronts per sample slower than one 64-row wavefront
-  // (output layer issued by both: 73.6 vs 82.1 TFLOP/s at B = 1024).  The per-equation
-  // split integrators (rhs_mfma.h kSplit) divide the output layer's channel groups between
-  // the two wavefronts instead: chosen when the ensemble leaves every SIMD at most ONE
-  // 64-row wavefront (B <= 1024 at N = 64) -- the second wavefront then fills the
-  // exposed latencies of the first (profiles/r4_ablation.txt).
-  // (launch_integrate applies that to the float32 persistent integrator only: the
-  // fused substep and the adaptive kernels have no split form)
+  // Two 32-row wavefronts per sample are never the geometry of the fused substep or
+  // the adaptive kernels; launch_integrate alone switches small float32 ensembles to
+  // the split integrators (rhs_mfma.h kSplit), where the measurement says it pays.
   (void)batch;
   return {64, 64};
 }

@@ -122,7 +122,7 @@ void adaptive_big_unit(const DevParams& p, const AdaptiveArgs& a, int blocks, hi
   template <> void adaptive_big_unit<K, CB, ROWS>(const DevParams&, const AdaptiveArgs&, int,    \
                                                   hipStream_t);
 #define DDD_DECLARE_BIG(K, CB) DDD_DECLARE_BIG_ROWS(K, CB, 64) DDD_DECLARE_BIG_ROWS(K, CB, 256)
-// the towers built (capi.hip: pick_tower embeds a net in the smallest one that holds it;
+// the towers built (capi.hip: decide_mfma picks the smallest one that holds the net, embed_tower pads it;
 // 7 taps x 64 filters is not built: its unrolled layers take > 20 minutes to compile)
 #define DDD_FOR_EACH_BIG_TOWER(X) X(3, 1) X(7, 1) X(5, 2)
 DDD_FOR_EACH_BIG_TOWER(DDD_DECLARE_BIG)
