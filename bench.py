@@ -807,73 +807,77 @@ def extra_configs(args, lib, world):
               launch_mode='persistent', state_dtype='float32')
   out = {}
   for name in wanted:
-    if name == 'kdv_n64_b4096':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'BASELINE.json configs[2]: KdV N=64, conv-net stencils, '
-          'batch 4096, midpoint at the equation time step', 4096,
-          **dict(base, equation='kdv', steps=1000))
-    elif name == 'ks_n256_b8192':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'BASELINE.json configs[3]: KS N=256, conv-net stencils, '
-          'batch 8192 TILED from 1024 distinct samples, midpoint at the equation time step '
-          '(400-step jobs; the 10k-step horizon is one longer launch of the same kernel, '
-          'tests/test_gpu_full_size.py runs it once)', 8192, unique=1024,
-          **dict(base, equation='ks', num_points=256, steps=400))
-    elif name == 'burgers_per_substep':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the headline workload with ONE FUSED LAUNCH PER RK '
-          'SUBSTEP for every sample (north_star structure; state through HBM every substep; '
-          'the ensemble advances as two half-ensembles on two streams, launches side by side)',
-          4096,
-          **dict(base, launch_mode='per_substep', steps=200))
-    elif name == 'burgers_per_step':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the headline workload with one launch per RK STEP (all '
-          'stages fused, state through HBM once per step): for callers that need the host '
-          'between steps but not between substeps', 4096,
-          **dict(base, launch_mode='per_step', steps=200))
-    elif name == 'rk_substep_external':
-      key, val = _external_driver_config(_variant(args, **base))
-    elif name == 'stream_fixed':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '
-          'KdV N=64 batch 262144 TILED from 4096 distinct samples, one launch per substep: '
-          'the HBM-bound kernel of the path', 262144, unique=4096,
-          **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_substep',
-                 steps=200))
-    elif name == 'stream_fixed_per_step':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the same fixed-stencil ensemble (KdV N=64 batch 262144 TILED '
-          'from 4096 distinct samples) with ALL stages of a midpoint step in one launch: the '
-          'stage input stays in the block\'s LDS tile, 8 B per grid point and step',
-          262144, unique=4096,
-          **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_step',
-                 steps=200))
-    elif name in ('tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096'):
-      hp = {'tower_k7_b4096': {'kernel_size': 7}, 'tower_f64_b4096': {'filter_size': 64},
-            'tower_k3_b4096': {'kernel_size': 3}}[name]
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the headline workload with hyper-parameters {} '
-          '(training.py:134-136 leaves them free): the MFMA towers with streamed weights; '
-          'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
-          **dict(base, hparams=json.dumps(hp), steps=200))
-    elif name == 'burgers_b256':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
-          'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '
-          'wavefronts, output layer split by channel groups', 256,
-          **dict(base, steps=1000))
-    elif name == 'differentiator_b1':
-      key, val = _differentiator_config(_variant(args, **base))
-    elif name == 'adaptive_rk23':
-      key, val = _adaptive_config(_variant(args, **base))
-    elif name == 'adaptive_kdv_n64_b4096':
-      key, val = _adaptive_config(_variant(args, **dict(base, equation='kdv')), name, 4096,
-                                  t_end=0.2, unique=1024)
-    else:
-      key, val = _adaptive_config(_variant(args, **dict(base, equation='ks', num_points=256)),
-                                  name, 1024, t_end=0.02, unique=256)
-    out[key] = val
+    try:
+      if name == 'kdv_n64_b4096':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'BASELINE.json configs[2]: KdV N=64, conv-net stencils, '
+            'batch 4096, midpoint at the equation time step', 4096,
+            **dict(base, equation='kdv', steps=1000))
+      elif name == 'ks_n256_b8192':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'BASELINE.json configs[3]: KS N=256, conv-net stencils, '
+            'batch 8192 TILED from 1024 distinct samples, midpoint at the equation time step '
+            '(400-step jobs; the 10k-step horizon is one longer launch of the same kernel, '
+            'tests/test_gpu_full_size.py runs it once)', 8192, unique=1024,
+            **dict(base, equation='ks', num_points=256, steps=400))
+      elif name == 'burgers_per_substep':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the headline workload with ONE FUSED LAUNCH PER RK '
+            'SUBSTEP for every sample (north_star structure; state through HBM every substep; '
+            'the ensemble advances as two half-ensembles on two streams, launches side by side)',
+            4096,
+            **dict(base, launch_mode='per_substep', steps=200))
+      elif name == 'burgers_per_step':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the headline workload with one launch per RK STEP (all '
+            'stages fused, state through HBM once per step): for callers that need the host '
+            'between steps but not between substeps', 4096,
+            **dict(base, launch_mode='per_step', steps=200))
+      elif name == 'rk_substep_external':
+        key, val = _external_driver_config(_variant(args, **base))
+      elif name == 'stream_fixed':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'fixed polynomial stencils (PolynomialDifferentiator), '
+            'KdV N=64 batch 262144 TILED from 4096 distinct samples, one launch per substep: '
+            'the HBM-bound kernel of the path', 262144, unique=4096,
+            **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_substep',
+                   steps=200))
+      elif name == 'stream_fixed_per_step':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the same fixed-stencil ensemble (KdV N=64 batch 262144 TILED '
+            'from 4096 distinct samples) with ALL stages of a midpoint step in one launch: the '
+            'stage input stays in the block\'s LDS tile, 8 B per grid point and step',
+            262144, unique=4096,
+            **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_step',
+                   steps=200))
+      elif name in ('tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096'):
+        hp = {'tower_k7_b4096': {'kernel_size': 7}, 'tower_f64_b4096': {'filter_size': 64},
+              'tower_k3_b4096': {'kernel_size': 3}}[name]
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the headline workload with hyper-parameters {} '
+            '(training.py:134-136 leaves them free): the MFMA towers with streamed weights; '
+            'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
+            **dict(base, hparams=json.dumps(hp), steps=200))
+      elif name == 'burgers_b256':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
+            'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '
+            'wavefronts, output layer split by channel groups', 256,
+            **dict(base, steps=1000))
+      elif name == 'differentiator_b1':
+        key, val = _differentiator_config(_variant(args, **base))
+      elif name == 'adaptive_rk23':
+        key, val = _adaptive_config(_variant(args, **base))
+      elif name == 'adaptive_kdv_n64_b4096':
+        key, val = _adaptive_config(_variant(args, **dict(base, equation='kdv')), name, 4096,
+                                    t_end=0.2, unique=1024)
+      else:
+        key, val = _adaptive_config(_variant(args, **dict(base, equation='ks', num_points=256)),
+                                    name, 1024, t_end=0.02, unique=256)
+      out[key] = val
+    except Exception as exc:   # one broken leg must not cost the headline line
+      sys.stderr.write('bench.py: config {} failed: {!r}\n'.format(name, exc))
+      out[name] = {'error': repr(exc)}
   return out
 
 
