@@ -814,8 +814,11 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
 
 // Wavefronts per SIMD the kernels are compiled for: two, except the four-wave groups of the
 // 64-channel towers (158 KB of LDS: one workgroup per CU anyway).
+#ifndef DDD_MIN_WAVES_AB
+#define DDD_MIN_WAVES_AB 2   // A/B (profiles/r4_ablation.txt): 1 = compile every kernel for ONE wavefront per SIMD
+#endif
 template <int kRows, int kWR, class TW>
-constexpr int min_waves() { return (TW::kCB == 2 && kRows != kWR) ? 1 : 2; }
+constexpr int min_waves() { return (TW::kCB == 2 && kRows != kWR) ? 1 : DDD_MIN_WAVES_AB; }
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
 struct Resident {
