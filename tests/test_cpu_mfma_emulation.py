@@ -250,3 +250,161 @@ def test_three_instruction_division_equals_ieee_division():
           or np.isfinite(big / s)
     if std != 1.0:
       assert np.mean(q != want) > 0.05     # the uncorrected product is NOT the quotient
+
+
+# ---------------------------------------------------------------------------
+# Towers with streamed weights (rhs_mfma.h Tower<K, CB>: input_layer_big,
+# hidden_layer_stream, final_layer4<NG, TW>; capi.hip pack_mfma_weights `big` branch
+# + embed_tower): K taps, CB blocks of 32 channels, activations in rows of 32 CB + 4.
+# ---------------------------------------------------------------------------
+def pack_input_big(w, b, taps, blocks):          # [h][s][lane]
+  steps = (taps + 2) // 2
+  packed = np.zeros((blocks, steps, 64))
+  for h in range(blocks):
+    for s in range(steps):
+      for lane in range(64):
+        k, ch = 2 * s + (lane >> 5), 32 * h + (lane & 31)
+        packed[h, s, lane] = w[k, 0, ch] if k < taps else (b[ch] if k == taps else 0.0)
+  return packed
+
+
+def pack_hidden_stream(w, b, taps, blocks):      # [group][block][lane][4] + bias [block][lane]
+  chans = 32 * blocks
+  groups = taps * chans // 8
+  packed = np.zeros((groups, blocks, 64, 4))
+  for g in range(groups):
+    for h in range(blocks):
+      for lane in range(64):
+        for e in range(4):
+          s = 4 * g + e
+          tap, cb, jj = s // (16 * blocks), (s // 16) % blocks, s % 16
+          cin, cout = 32 * cb + 16 * (lane >> 5) + jj, 32 * h + (lane & 31)
+          packed[g, h, lane, e] = w[tap, cin, cout]
+  bias = np.zeros((blocks, 64))
+  for h in range(blocks):
+    bias[h, :32] = b[32 * h:32 * h + 32]
+  return packed, bias
+
+
+def embed(kernels, biases, taps, chans):         # capi.hip: embed_tower
+  out_k, out_b = [], []
+  for l, (w, b) in enumerate(zip(kernels, biases)):
+    k_true = w.shape[0]
+    shift = (taps - 1) // 2 - k_true // 2
+    cin = 1 if l == 0 else chans
+    cout = w.shape[2] if l == len(kernels) - 1 else chans
+    wp = np.zeros((taps, cin, cout), w.dtype)
+    wp[shift:shift + k_true, :w.shape[1], :w.shape[2]] = w
+    bp = np.zeros(cout, b.dtype)
+    bp[:b.shape[0]] = b
+    out_k.append(wp)
+    out_b.append(bp)
+  return out_k, out_b
+
+
+def emulate_big_tower(un_rows, n, kernels, biases, taps, blocks, groups):
+  """One-wave geometry generalised to 256 rows (four wavefronts): the operand
+  gathers of input_layer_big / hidden_layer_stream / final_layer4<NG, TW>."""
+  chans, hs, left = 32 * blocks, 32 * blocks + 4, taps // 2
+  rows_used = (ROWS // n) * n
+  relu = lambda x: np.maximum(x, 0.0)
+  bufs = [np.zeros((ROWS, hs)), np.zeros((ROWS, hs))]
+  j, half = LANES & 31, LANES >> 5
+  w_in = pack_input_big(kernels[0], biases[0], taps, blocks)
+  steps = (taps + 2) // 2
+  for wave in range(4):
+    for t in range(2):
+      trow = wave * 64 + t * 32 + j
+      ops = []
+      for s in range(steps):
+        if 2 * s < taps - 1:
+          k = np.where(half == 1, 2 * s + 1, 2 * s)
+          ops.append(un_rows[tile_src_row(trow, k - left, n, rows_used)])
+        else:   # last step: tap K - 1 beside the bias row
+          ops.append(np.where(half == 1, 1.0,
+                              un_rows[tile_src_row(trow, taps - 1 - left, n, rows_used)]))
+      for h in range(blocks):
+        acc = np.zeros((64, 16))
+        for s in range(steps):
+          acc = mfma32(w_in[h, s], ops[s], acc)
+        for qd in range(4):
+          for c in range(4):
+            bufs[0][trow, 32 * h + 8 * qd + 4 * half + c] = relu(acc)[:, 4 * qd + c]
+  src, dst = bufs
+  for l in range(1, len(kernels) - 1):
+    packed, bias = pack_hidden_stream(kernels[l], biases[l], taps, blocks)
+    dst[:] = 0
+    for wave in range(4):
+      for t in range(2):
+        trow = wave * 64 + t * 32 + j
+        acc = [np.zeros((64, 16)) for _ in range(blocks)]
+        for g in range(packed.shape[0]):
+          tap, cb, quad = g // (4 * blocks), (g // 4) % blocks, g % 4
+          rows = tile_src_row(trow, tap - left, n, rows_used)
+          for e in range(4):
+            bop = src[rows, 32 * cb + 16 * half + 4 * quad + e]
+            for h in range(blocks):
+              acc[h] = mfma32(packed[g, h, :, e], bop, acc[h])
+        for h in range(blocks):
+          acc[h] = mfma32(bias[h], np.ones(64), acc[h])
+          for qd in range(4):
+            for c in range(4):
+              dst[trow, 32 * h + 8 * qd + 4 * half + c] = relu(acc[h])[:, 4 * qd + c]
+    src, dst = dst, src
+  # output layer: k = tap * chans + c in natural order, K C + 1 reduction steps
+  w, b = kernels[-1], biases[-1]
+  n_ch, kc = w.shape[2], taps * chans
+  fin_k = kc + 1
+  packed = np.zeros(((fin_k * groups + 15) // 16, 64))
+  wk = w.reshape(kc, n_ch)
+  for k in range(fin_k):
+    for grp in range(groups):
+      q = k * groups + grp
+      for r in range(4):
+        ch = 4 * grp + r
+        if ch < n_ch:
+          packed[q // 16, 4 * (q % 16) + r] = wk[k, ch] if k < kc else b[ch]
+  out = np.zeros((ROWS, 4 * groups))
+  per_tap = chans // 4
+  for wave in range(4):
+    row = wave * 64 + LANES
+    acc = [np.zeros((64, 4)) for _ in range(groups)]
+    for og in range(taps * per_tap):
+      tap, c4 = og // per_tap, og % per_tap
+      rows = tile_src_row(row, tap - left, n, rows_used)
+      for e in range(4):
+        bop = src[rows, 4 * c4 + e]
+        for grp in range(groups):
+          q = (og * 4 + e) * groups + grp
+          acc[grp] = mfma4(packed[q // 16], bop, acc[grp], q % 16)
+    for grp in range(groups):
+      q = kc * groups + grp
+      acc[grp] = mfma4(packed[q // 16], np.ones(64), acc[grp], q % 16)
+      out[row, 4 * grp:4 * grp + 4] = acc[grp]
+  return out
+
+
+@pytest.mark.parametrize('n,num_layers,c_out,k_true,f_true,taps,blocks', [
+    (64, 3, 9, 7, 32, 7, 1), (64, 3, 12, 5, 64, 5, 2), (32, 3, 8, 3, 32, 3, 1),
+    (96, 4, 11, 6, 20, 7, 1),      # embedded: 6 taps x 20 filters in 7 x 32
+    (128, 2, 9, 4, 40, 5, 2),      # embedded: 4 taps x 40 filters in 5 x 64, no hidden layer
+])
+def test_emulated_streamed_towers_match_oracle(n, num_layers, c_out, k_true, f_true, taps, blocks):
+  rs = np.random.RandomState(n + taps + blocks)
+  shapes = [(k_true, 1 if l == 0 else f_true, c_out if l == num_layers - 1 else f_true)
+            for l in range(num_layers)]
+  kernels = [rs.randn(*s).astype(np.float32) * 0.3 for s in shapes]
+  biases = [rs.randn(s[2]).astype(np.float32) * 0.1 for s in shapes]
+  samples = ROWS // n
+  u = rs.randn(samples, n).astype(np.float32)
+  spec = dict(standard_deviation=0.8, conv_kernels=kernels, conv_biases=biases,
+              num_layers=num_layers, nonlinearity='relu')
+  want = oracle.conv_stack(u, spec)                      # the TRUE net
+  un_rows = np.zeros(ROWS)
+  un_rows[:samples * n] = (u / np.float32(0.8)).reshape(-1)
+  pk, pb = embed(kernels, biases, taps, 32 * blocks)
+  groups = (c_out + 3) // 4
+  net = emulate_big_tower(un_rows, n, pk, pb, taps, blocks, groups)
+  got = net[:samples * n, :c_out].reshape(samples, n, c_out)
+  np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+  assert np.all(net[:samples * n, c_out:] == 0)
