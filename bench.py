@@ -84,7 +84,8 @@ CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burger
                 'rk_substep_external', 'stream_fixed', 'stream_fixed_per_step',
                 'differentiator_b1', 'adaptive_rk23',
                 'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024',
-                'tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096', 'burgers_b256')
+                'tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096', 'burgers_b256',
+                'one_layer_b4096')
 
 
 def parse_args(argv=None):
@@ -858,7 +859,14 @@ def extra_configs(args, lib, world):
             '(training.py:134-136 leaves them free): the MFMA towers with streamed weights; '
             'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
             **dict(base, hparams=json.dumps(hp), steps=200))
-      elif name == 'burgers_b256':
+      elif name == 'one_layer_b4096':
+      key, val = _fixed_step_config(
+          args, lib, world, name, 'the model of the reference\'s own integration tests '
+          '(integrate_test.py:48: num_layers = 1): coefficients affine in the 5 neighbouring '
+          'values, folded on the host, evaluated on the VALU route of the MFMA-path kernels '
+          '(111 FMA per grid point and evaluation: latency-bound, no matrix work)', 4096,
+          **dict(base, hparams=json.dumps({'num_layers': 1}), steps=1000))
+    elif name == 'burgers_b256':
         key, val = _fixed_step_config(
             args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
             'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '

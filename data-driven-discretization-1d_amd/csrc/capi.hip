@@ -639,6 +639,13 @@ void embed_tower(const ddd::DevParams& dp, const std::vector<float>& wv, int tow
   net->weights = padded->data();
 }
 
+// One-layer nets the MFMA-path kernels carry on their VALU route (DevParams::linear_taps).
+bool linear_eligible(const ddd::DevParams& dp) {
+  return !dp.fixed && dp.L == 1 && dp.target == ddd::TARGET_COEFFICIENTS &&
+         !(dp.pao <= 0 && dp.unbiased) && dp.D <= 3 && dp.G <= ddd::kGMax && dp.K <= 7 &&
+         dp.K * dp.D <= ddd::kChMax;
+}
+
 void decide_mfma(ddd_model* m) {
   const ddd::DevParams& dp = m->dp;
   char why[256] = "";
@@ -654,7 +661,8 @@ void decide_mfma(ddd_model* m) {
   // = 9 and polynomial_accuracy_order = 0 with three derivatives
   // (training_test.py:56-57).
   bool wide = dp.G > ddd::kGMax;
-  if (!dp.fixed) {
+  const bool linear = linear_eligible(dp);
+  if (!dp.fixed && !linear) {
     // direct heads (space_derivatives / time_derivative / flux: D or 1 output
     // channels) and polynomial_accuracy_order = 0 (D x G coefficient channels,
     // no projection) run on the run-time-parameterised MFMA kernels
@@ -673,7 +681,7 @@ void decide_mfma(ddd_model* m) {
     if (wide && m->tower_k == 3) m->tower_k = 5;
     if (wide && m->big()) no("wide stencils / > 16 output channels with a tower other than 5 x 32");
   }
-  if (!ok || dp.fixed) { m->tower_k = 5; m->tower_cb = 1; }
+  if (!ok || dp.fixed || linear) { m->tower_k = 5; m->tower_cb = 1; }
   m->wide = ok && wide;
   m->mfma_ok = ok;
   m->mfma_reason = why;
@@ -1254,7 +1262,38 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
   }
   if (!rc) {
     decide_mfma(m);
-    if (m->mfma_ok) {
+    if (m->mfma_ok && linear_eligible(dp)) {
+      // coeff[d][g] = B[d][g] + sum_k M[k][d][g] (u / std)[x + k - K/2]: the conv layer, the
+      // null-space projection and the accuracy bias folded in float64, rounded once
+      std::memset(dp.ns8, 0, sizeof(dp.ns8));
+      std::memset(dp.bias8, 0, sizeof(dp.bias8));
+      const float* w = wv.data() + dp.w_off[0];   // [K][1][C_out]
+      const float* b = wv.data() + dp.b_off[0];
+      for (int d = 0; d < dp.D; ++d)
+        for (int g = 0; g < dp.G; ++g) {
+          if (projected) {
+            double acc = (double)bias[d * dp.G + g];
+            for (int j = 0; j < dp.in_size[d]; ++j)
+              acc += (double)b[dp.in_start[d] + j] * (double)nullspace[dp.ns_off[d] + j * dp.G + g];
+            dp.bias8[d][g] = (float)acc;
+            for (int k = 0; k < dp.K; ++k) {
+              double mk = 0.0;
+              for (int j = 0; j < dp.in_size[d]; ++j)
+                mk += (double)w[(size_t)k * dp.C_out + dp.in_start[d] + j] *
+                      (double)nullspace[dp.ns_off[d] + j * dp.G + g];
+              dp.ns8[k * dp.D + d][g] = (float)mk;
+            }
+          } else {   // polynomial_accuracy_order 0: the layer emits the coefficients themselves
+            dp.bias8[d][g] = b[d * dp.G + g];
+            for (int k = 0; k < dp.K; ++k)
+              dp.ns8[k * dp.D + d][g] = w[(size_t)k * dp.C_out + d * dp.G + g];
+          }
+        }
+      dp.linear_taps = dp.K;
+      dp.folded = 0;
+      dp.dsel_bits = 0;
+      dp.dsel_valid = 0;
+    } else if (m->mfma_ok) {
       const bool fold_shape = dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
       rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr,
                                 dp.target == ddd::TARGET_COEFFICIENTS && !projected &&

@@ -40,6 +40,14 @@ struct DevParams {
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
   int weno;            // fixed only: derivatives 0 / 1 are WENO5 reconstructions
+  // One-layer nets (num_layers = 1: the model of the reference's own integration tests,
+  // integrate_test.py:48): the coefficients are AFFINE in the K neighbouring values,
+  //   coeff[d][g] = B[d][g] + sum_k M[k][d][g] (u / std)[x + k - K/2],
+  // with B / M folded on the host (float64) from the conv layer, the null space and the
+  // accuracy bias.  linear_taps = K > 0: the MFMA-path kernels skip the tower like a fixed
+  // model and add the M terms on the VALU; M[k][d] is row 4 + k D + d of the LDS table
+  // (ns8), B is bias8.  The generic kernel ignores these fields and runs the true net.
+  int linear_taps;
   int dpp_rol;         // 1: `v_mov_b32_dpp wave_rol:1` verified on this device (capi.hip)
   int target, L, F, K, act, C_out, pao, unbiased;
   int in_start[kMaxDerivs], in_size[kMaxDerivs], ns_off[kMaxDerivs];

@@ -938,7 +938,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   const unsigned long long dsel_bits = kSpec ? 0ull : opaque_scalar(p.dsel_bits);
   const int rt_groups = kSpec ? 0 : opaque_scalar(p.rt_groups);
   const bool flux_form = kSpec ? spec_flux_form(kEq) : (p.conservative != 0);
-  const bool fixed = kSpec ? false : (p.fixed != 0);
+  const bool fixed = kSpec ? false : (p.fixed != 0 || p.linear_taps != 0);   // no conv tower to run
   const bool folded = kSpec ? spec_folded(kSpec ? kEq : 0) : (p.folded != 0);
   // what the tower predicts (model.py:579-640): stencil coefficients (default),
   // the spatial derivatives, the time derivative or the flux themselves
@@ -1334,6 +1334,34 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       }
     }
   }
+  if constexpr (!kSpec && !kWide) {
+    if (p.linear_taps != 0) {
+      // one-layer net: coeff += sum_k M[k][d] (u / std)[x + k - K/2]  (DevParams::linear_taps);
+      // the bias part B is added with the table rows below
+      const int taps = opaque_scalar(p.linear_taps), left = taps >> 1;
+      for (int k = 0; k < taps; ++k) {   // wave-uniform trip count
+        const float uk = sm.u[pow2 ? (((ln.pos + k - left) & (p.N - 1)) | ln.base)
+                                   : wrap_row(ln.base, ln.pos, k - left, p.N)];
+        const float qk = uk * p.inv_stddev;
+        float unk = fmaf(fmaf(-qk, p.stddev, uk), p.inv_stddev, qk);   // u / std, as in the tower
+        if (p.exact_div) unk = uk / p.stddev;
+#pragma unroll
+        for (int d = 0; d < kMaxDerivs - 1; ++d) {
+          if (d >= nD) continue;
+          const float* __restrict__ row = sm.tab + (4 + k * nD + d) * kGW;
+          const float4 m0 = *reinterpret_cast<const float4*>(row);
+          const float4 m1 = *reinterpret_cast<const float4*>(row + 4);
+          cf[d][0] = fmaf(unk, m0.x, cf[d][0]); cf[d][1] = fmaf(unk, m0.y, cf[d][1]);
+          cf[d][2] = fmaf(unk, m0.z, cf[d][2]); cf[d][3] = fmaf(unk, m0.w, cf[d][3]);
+          cf[d][4] = fmaf(unk, m1.x, cf[d][4]); cf[d][5] = fmaf(unk, m1.y, cf[d][5]);
+          cf[d][6] = fmaf(unk, m1.z, cf[d][6]); cf[d][7] = fmaf(unk, m1.w, cf[d][7]);
+        }
+      }
+      // four-wave groups: a faster wavefront rewrites sm.u as soon as it enters the next
+      // evaluation -- not before every wavefront has read its neighbours here
+      if (!kOneWave) group_barrier<kRows, kWR>();
+    }
+  }
   if (!kSpec && !fixed && p.pao <= 0 && p.unbiased) {
     // ensure_unbiased_coefficients (model.py:471-475): subtract the mean over
     // the stencil (same order of operations as the generic kernel)
@@ -1499,7 +1527,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
-  if (!p.fixed && TW::kDefault) {   // (other towers stream every layer's weights: nothing resident)
+  if (!p.fixed && !p.linear_taps && TW::kDefault) {   // (other towers stream every layer's weights)
     load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
     // loop invariants the specialised one-wave integrators keep resident
@@ -1535,7 +1563,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     res.frc_slot = (fast && tid < spg * p.n_k * 2)
                        ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
   }
-  if (!p.fixed && kHoist && (kWR == 64 || p.w_final4_split != nullptr))
+  if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || p.w_final4_split != nullptr))
     lane_offsets<kRows, kWR>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)

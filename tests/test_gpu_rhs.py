@@ -293,14 +293,54 @@ def test_other_towers_on_mfma(overrides):
 
 
 @pytest.mark.parametrize('overrides', [
-    dict(num_layers=1), dict(filter_size=96), dict(kernel_size=9),
+    dict(num_layers=1), dict(num_layers=1, kernel_size=3), dict(num_layers=1, kernel_size=7),
+    dict(num_layers=1, polynomial_accuracy_order=0),
+    dict(num_layers=1, filter_size=8, nonlinearity='tanh'),    # (neither is used by a 1-layer net)
+])
+def test_one_layer_nets_on_the_valu_route(overrides):
+  """num_layers = 1 -- the model of the reference's own integration tests
+  (integrate_test.py:48: model_kwargs = dict(num_layers=1, filter_size=32)) -- has no
+  hidden activations: its coefficients are affine in the K neighbouring values, folded on
+  the host (conv layer x null space + accuracy bias) and evaluated on the VALU route of the
+  MFMA-path kernels (DevParams::linear_taps) instead of the generic kernel.  Every equation
+  form, both geometries, all views, 10 steps, launch modes bit-equal, generic kernel agrees."""
+  for equation, conservative, num_points in (('burgers', True, 64), ('burgers', False, 32),
+                                             ('kdv', True, 96), ('ks', False, 64),
+                                             ('ks', True, 256)):
+    model = make_model(equation, conservative, num_points=num_points, resample_factor=2,
+                       **overrides)
+    want_kernel = 'mfma_f32_r64' if 64 % num_points == 0 else 'mfma_f32_r256'
+    if overrides.get('kernel_size', 5) * len(model.equation.DERIVATIVE_ORDERS) > 16:
+      want_kernel = 'generic'   # (7 taps x 3 derivatives: more table rows than the LDS table holds)
+    assert model.kernel_name == want_kernel, (overrides, model.kernel_name)
+    batch = 7
+    y0 = random_phase_ic(model.equation, batch)
+    forcing = batch_forcing(batch)
+    model.set_forcing(forcing)
+    valu_err = _check_all_views(model, y0, 0.2, forcing, None)
+    dt = 1e-5
+    got = model.integrate_fixed(y0, 10, dt=dt, save_every=10).cpu().numpy()
+    want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 10, 10, y0,
+                                  forcing=forcing if equation == 'burgers' else None)
+    assert rel_err(got, want) < TOL, (equation, overrides)
+    per_substep = model.integrate_fixed(y0, 10, dt=dt, save_every=10,
+                                        launch_mode='per_substep').cpu().numpy()
+    np.testing.assert_array_equal(got, per_substep)
+    model.set_kernel('generic')
+    generic_err = _check_all_views(model, y0, 0.2, forcing, None)
+    print(equation, num_points, overrides, valu_err, generic_err)
+
+
+@pytest.mark.parametrize('overrides', [
+    dict(num_layers=1, polynomial_accuracy_order=0, ensure_unbiased_coefficients=True),
+    dict(filter_size=96), dict(kernel_size=9),
     dict(kernel_size=7, filter_size=64),
     dict(coefficient_grid_min_size=13), dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
   """Configurations the MFMA path does not cover (more than 64 filters or 7 taps, 7
-  taps together with 64 filters, one-layer nets, stencils wider than 12) run on
-  the generic kernel (never on the CPU)."""
+  taps together with 64 filters, one-layer nets with mean-subtracted coefficients,
+  stencils wider than 12) run on the generic kernel (never on the CPU)."""
   conservative = not overrides.get('ensure_unbiased_coefficients', False)
   model = make_model('burgers', conservative, num_points=64, **overrides)
   if overrides.get('num_layers', 3) != 0:
