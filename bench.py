@@ -860,13 +860,13 @@ def extra_configs(args, lib, world):
             'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
             **dict(base, hparams=json.dumps(hp), steps=200))
       elif name == 'one_layer_b4096':
-      key, val = _fixed_step_config(
-          args, lib, world, name, 'the model of the reference\'s own integration tests '
-          '(integrate_test.py:48: num_layers = 1): coefficients affine in the 5 neighbouring '
-          'values, folded on the host, evaluated on the VALU route of the MFMA-path kernels '
-          '(111 FMA per grid point and evaluation: latency-bound, no matrix work)', 4096,
-          **dict(base, hparams=json.dumps({'num_layers': 1}), steps=1000))
-    elif name == 'burgers_b256':
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the model of the reference\'s own integration tests '
+            '(integrate_test.py:48: num_layers = 1): coefficients affine in the 5 neighbouring '
+            'values, folded on the host, evaluated on the VALU route of the MFMA-path kernels '
+            '(111 FMA per grid point and evaluation: latency-bound, no matrix work)', 4096,
+            **dict(base, hparams=json.dumps({'num_layers': 1}), steps=1000))
+      elif name == 'burgers_b256':
         key, val = _fixed_step_config(
             args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
             'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '
