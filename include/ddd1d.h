@@ -168,6 +168,13 @@ typedef struct ddd_model ddd_model;
  *             PolynomialAccuracyLayer.nullspace (polynomials.py:246-264);
  *             NULL unless target = coefficients with accuracy order > 0.
  *   bias      [D][G] float32 of PolynomialAccuracyLayer.bias; same condition.
+ * Which kernel family serves the model (ddd_kernel_name; training.py:127-141 leaves
+ * these hyper-parameters free): 8 <= num_points <= 256, >= 2 layers, kernel_size <= 7 and
+ * filter_size <= 64 (not both > 5 and > 32): the f32-MFMA kernels -- 5 taps x 32 filters with
+ * per-equation kernels, 7 x 32 / 5 x 64 / 3 x 32 with streamed weights, nets in between
+ * embedded exactly with zero weights; num_layers = 1 with coefficient output: affine
+ * coefficients folded here, evaluated on the VALU route of the same kernels; everything
+ * else (larger nets or grids, num_points < 8, stencils > 12 points): the generic kernel.
  */
 DDD_API int ddd_model_create(const ddd_config* cfg, const float* weights,
                      size_t n_weights, const float* nullspace,
