@@ -408,6 +408,28 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
     dist.broadcast(r, 0)
     reps = int(r[0])
 
+  # 1b. N > 1: the SAME per-rank workload on rank 0 ALONE (the other ranks idle at the
+  # barrier), so that one invocation yields the 1 -> N point of the weak-scaling curve
+  # even when no separate --gpus 1 run of this shard size exists ("scaling_detail")
+  solo = None
+  if world > 1:
+    barrier()
+    if dist.get_rank() == 0:
+      model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
+                            save_every=args.steps, launch_mode=args.launch_mode,
+                            state_dtype=args.state_dtype, out=final)
+      torch.cuda.synchronize()
+      solo0 = time.perf_counter()
+      start_evt.record()
+      for rep in range(reps):
+        model.integrate_fixed(y0, args.steps, dt=dt, t0=0.0, scheme=args.scheme,
+                              save_every=args.steps, launch_mode=args.launch_mode,
+                              state_dtype=args.state_dtype, out=finals[rep & 1])
+      stop_evt.record()
+      torch.cuda.synchronize()
+      solo = {'wall': time.perf_counter() - solo0, 'kernel_ms': start_evt.elapsed_time(stop_evt)}
+    barrier()
+
   # 2. the contract's warm-up steps
   if args.warmup > 0:
     job(args.warmup)
@@ -469,7 +491,7 @@ def measure(args, model, y0_host, world, n, batch, sample_clocks=False):
                      'must not be quoted\n'.format(batch))
   return dict(wall=wall, kernel_ms=kernel_ms, reps=reps, finite=finite,
               preheat_ms=heated, preheat_launches=heat_launches, clocks=clocks,
-              per_rank=per_rank)
+              per_rank=per_rank, solo=solo)
 
 
 def summarize(args, eq, model, m, world, n, batch, stages):
@@ -528,6 +550,29 @@ def summarize(args, eq, model, m, world, n, batch, stages):
       'value': total_points / m['wall'],
       'ms_per_step': m['wall'] * 1e3 / steps_timed,
       'roofline': roofline,
+  }
+
+
+def scaling_detail(args, m, world, n, batch, value):
+  """N > 1: rank 0's throughput on the same per-rank workload with the other ranks idle
+  (measured in the same invocation, right before the timed region), the whole job's
+  value against N times that, and the process group as torch.distributed reports it
+  (backend "nccl" = RCCL on ROCm).  The contract's `scaling` key stays "weak"; the
+  driver computes its own efficiency from separate runs -- this is the self-check."""
+  if world <= 1 or m.get('solo') is None:
+    return None
+  import torch.distributed as dist
+  n1_value = batch * n * args.steps * m['reps'] / m['solo']['wall']
+  return {
+      'n1_value': n1_value,
+      'n1_ms_per_step': m['solo']['wall'] * 1e3 / (args.steps * m['reps']),
+      'n1_kernel_ms': m['solo']['kernel_ms'],
+      'n1_batch': batch,
+      'efficiency': value / (world * n1_value),
+      'nranks': dist.get_world_size(),
+      'backend': dist.get_backend(),
+      'note': 'rank 0 alone on its shard (others idle at a barrier), same steps x reps; '
+              'efficiency = value / (n_gpus x n1_value)',
   }
 
 
@@ -861,10 +906,10 @@ def extra_configs(args, lib, world):
             **dict(base, hparams=json.dumps(hp), steps=200))
       elif name == 'one_layer_b4096':
         key, val = _fixed_step_config(
-            args, lib, world, name, 'the model of the reference\'s own integration tests '
-            '(integrate_test.py:48: num_layers = 1): coefficients affine in the 5 neighbouring '
-            'values, folded on the host, evaluated on the VALU route of the MFMA-path kernels '
-            '(111 FMA per grid point and evaluation: latency-bound, no matrix work)', 4096,
+            args, lib, world, name, 'num_layers = 1 (a hyper-parameter create_hparams admits; '
+            'NOT what the reference\'s integration tests train -- integrate_test.py:48 never passes '
+            'its model_kwargs): coefficients affine in the 5 neighbouring values, folded on the '
+            'host; 111 FMA per grid point and evaluation, no matrix work', 4096,
             **dict(base, hparams=json.dumps({'num_layers': 1}), steps=1000))
       elif name == 'burgers_b256':
         key, val = _fixed_step_config(
@@ -1027,6 +1072,7 @@ def main():
         'secondary': secondary,
         'configs': configs,
         'per_rank': m['per_rank'],
+        'scaling_detail': scaling_detail(args, m, world, n, batch, s['value']),
         'clocks': m['clocks'],
     }
     if not m['finite']:

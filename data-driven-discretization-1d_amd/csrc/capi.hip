@@ -21,6 +21,7 @@
 #include "probe_kernels.h"
 #endif
 #include "rhs_generic.h"
+#include "rhs_lean.h"
 #include "rhs_mfma.h"
 #include "rhs_spectral.h"
 #include "rhs_stream.h"
@@ -40,6 +41,7 @@ struct DebugOptions {
   int no_fold = 0;       // keep the projection out of the output layer (D <= 2 models)
   int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
   int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
+  int no_lean = 0;       // the MFMA-path kernels (tower skipped) instead of rhs_lean.h
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
   int substep_parts = 0; // A/B: sample slabs advanced side by side in the per-substep modes (0: auto)
@@ -154,6 +156,22 @@ int make_tableau(int scheme, ddd::Tableau* tab) {
   }
 }
 
+// The per-stage products of a fixed-step launch in the kernels' own arithmetic (float
+// state: a[s] * (float)dt in float32; float64 state: (double)a[s] * dt; stage times
+// c[s] * dt in float64) -- dev_params.h: StageConsts.
+ddd::StageConsts make_stage_consts(const ddd::Tableau& tab, double dt) {
+  ddd::StageConsts sc{};
+  const float h = (float)dt;
+  for (int s = 0; s < ddd::kMaxStages; ++s) {
+    const volatile float ah = tab.a[s] * h, bh = tab.b[s] * h;   // (volatile: one rounding each,
+    const volatile double ahd = (double)tab.a[s] * dt;            //  no host-side contraction)
+    const volatile double bhd = (double)tab.b[s] * dt, ct = tab.c[s] * dt;
+    sc.ah[s] = ah; sc.bh[s] = bh; sc.ahd[s] = ahd; sc.bhd[s] = bhd; sc.ct[s] = ct;
+    if (s < tab.stages && tab.b[s] != 0.0f) sc.b_nonzero |= 1 << s;
+  }
+  return sc;
+}
+
 }  // namespace
 
 struct ddd_model {
@@ -167,6 +185,7 @@ struct ddd_model {
   bool spec_folded = false;          // w_final4 (specialised kernels) holds the folded output layer
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
   bool last_launch_split = false;    // ... the persistent integrator with two 32-row wavefronts per sample
+  bool last_launch_lean = false;     // ... the lane == grid point kernel of rhs_lean.h
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
@@ -346,6 +365,12 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
   const float* weights = net.weights;
   const int hidden = dp.L - 2;
   const int tk = m->tower_k, tcb = m->tower_cb, tc = 32 * tcb;   // the (padded) net: tk taps, tc filters
+  // relu towers run on activations scaled by 2^-kReluShift (dev_params.h: the relu is the
+  // VALU's [0, 1] clamp on a packed add): the input layer's weights and every bias row of
+  // the tower carry `dn`, the output layer's weights `up`.  Exact: powers of two.
+  const bool relu_clamp = dp.act == ddd::ACT_RELU && ddd::kReluShift != 0;
+  const float dn = relu_clamp ? std::ldexp(1.0f, -ddd::kReluShift) : 1.0f;
+  const float up = relu_clamp ? std::ldexp(1.0f, ddd::kReluShift) : 1.0f;
   if (m->big()) {
     // streamed layouts of rhs_mfma.h: input_layer_big / hidden_layer_stream
     const int in_steps = (tk + 2) / 2;
@@ -358,7 +383,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
           for (int lane = 0; lane < 64; ++lane) {
             const int k = 2 * s + (lane >> 5), ch = 32 * h + (lane & 31);
             packed[((size_t)h * in_steps + s) * 64 + lane] =
-                k < tk ? w[k * tc + ch] : k == tk ? b[ch] : 0.0f;
+                dn * (k < tk ? w[k * tc + ch] : k == tk ? b[ch] : 0.0f);
           }
       int rc = upload(packed, &m->d_w_input);
       if (rc) return rc;
@@ -384,7 +409,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
               }
         float* bias = dst + (size_t)groups * tcb * 64 * 4;
         for (int h = 0; h < tcb; ++h)
-          for (int lane = 0; lane < 32; ++lane) bias[h * 64 + lane] = b[32 * h + lane];
+          for (int lane = 0; lane < 32; ++lane) bias[h * 64 + lane] = dn * b[32 * h + lane];
       }
       int rc = upload(packed, &m->d_w_hidden);
       if (rc) return rc;
@@ -399,7 +424,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     for (int s = 0; s < ddd::mfma::kInSteps; ++s)
       for (int lane = 0; lane < 64; ++lane) {
         const int k = 2 * s + (lane >> 5), ch = lane & 31;
-        packed[s * 64 + lane] = k < 5 ? w[k * 32 + ch] : b[ch];
+        packed[s * 64 + lane] = dn * (k < 5 ? w[k * 32 + ch] : b[ch]);
       }
     int rc = upload(quad_rows(packed.data(), ddd::mfma::kInSteps), &m->d_w_input);
     if (rc) return rc;
@@ -419,7 +444,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
         }
       }
       for (int lane = 0; lane < 64; ++lane)
-        dst[80 * 64 + lane] = (lane >> 5) == 0 ? b[lane & 31] : 0.0f;
+        dst[80 * 64 + lane] = (lane >> 5) == 0 ? dn * b[lane & 31] : 0.0f;
     }
     std::vector<float> stored;   // every hidden layer padded on its own (load_hidden)
     for (int h = 0; h < hidden; ++h) {
@@ -505,7 +530,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
             if (renumber && ch >= n_ch) continue;   // folded columns are contiguous already
             if (src >= cout_n) continue;
             packed4[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
-                k < 160 ? w[(size_t)k * cout_n + src] : b[src];
+                k < 160 ? up * w[(size_t)k * cout_n + src] : b[src];
           }
         }
       return packed4;
@@ -544,7 +569,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
               const int ch = 4 * (first_group + gi) + r;
               if (ch >= cout_n) continue;
               packed[((size_t)row0 + q / 16) * 64 + 4 * (q % 16) + r] =
-                  k < kc ? w[(size_t)k * cout_n + ch] : b[ch];
+                  k < kc ? up * w[(size_t)k * cout_n + ch] : b[ch];
             }
           }
       };
@@ -587,7 +612,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
                 const int ch = 4 * (g0 + gi) + r;
                 if (ch >= n_ch || ch >= cout_n) continue;
                 chunk[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
-                    k < 160 ? w[(size_t)k * cout_n + ch] : b[ch];
+                    k < 160 ? up * w[(size_t)k * cout_n + ch] : b[ch];
               }
             }
           const std::vector<float> q4 = quad_rows(chunk.data(), chunk_rows);
@@ -832,11 +857,11 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     else
       hipLaunchKernelGGL(ddd::stream::fixed_substep_kernel<1>, dim3(blocks),
                          dim3(ddd::stream::kThreads), 0, stream, m->dp, a);
-    m->last_launch_streamed = true;
+    m->last_launch_streamed = true; m->last_launch_lean = false;
     DDD_HIP(hipGetLastError());
     return DDD_OK;
   }
-  m->last_launch_streamed = false;
+  m->last_launch_streamed = false; m->last_launch_lean = false;
   m->last_launch_split = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
@@ -948,11 +973,40 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   ddd::launch::integrate_runtime(kRows, kWR, f64, hoist, m->dp, a, blocks, stream);
 }
 
+// The persistent launch of fixed-stencil models and one-layer nets (rhs_lean.h): one
+// instantiation per (taps, derivatives, stencil-column pairs).
+template <int kK, int kD>
+void launch_lean_kd(int pairs, const ddd::DevParams& dp, const ddd::IntegrateArgs& a, int blocks,
+                    hipStream_t stream) {
+  if (pairs == 3)
+    hipLaunchKernelGGL((ddd::lean::integrate_kernel<kK, kD, 3>), dim3(blocks), dim3(64), 0, stream, dp, a);
+  else
+    hipLaunchKernelGGL((ddd::lean::integrate_kernel<kK, kD, 4>), dim3(blocks), dim3(64), 0, stream, dp, a);
+}
+bool launch_lean(const ddd_model* m, const ddd::IntegrateArgs& a, hipStream_t stream) {
+  const ddd::DevParams& dp = m->dp;
+  if (!ddd::lean::supports(dp)) return false;
+  const int taps = dp.fixed ? 0 : dp.linear_taps, pairs = ddd::lean::column_pairs(dp.G);
+  const int blocks = (a.batch + 64 / dp.N - 1) / (64 / dp.N);
+  const int derivs = dp.D;
+#define DDD_LEAN_CASE(TAPS, DERIVS) \
+  if (taps == TAPS && derivs == DERIVS) {                                 \
+    launch_lean_kd<TAPS, DERIVS>(pairs, dp, a, blocks, stream);           \
+    return true;                                                          \
+  }
+  DDD_LEAN_CASE(0, 1) DDD_LEAN_CASE(0, 2) DDD_LEAN_CASE(0, 3) DDD_LEAN_CASE(0, 4)
+  DDD_LEAN_CASE(3, 1) DDD_LEAN_CASE(3, 2) DDD_LEAN_CASE(3, 3)
+  DDD_LEAN_CASE(5, 1) DDD_LEAN_CASE(5, 2) DDD_LEAN_CASE(5, 3)
+  DDD_LEAN_CASE(7, 1) DDD_LEAN_CASE(7, 2)
+#undef DDD_LEAN_CASE
+  return false;   // (other tap counts: the MFMA-path kernels with the tower skipped)
+}
+
 template <typename ST>
 int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   if (a.batch == 0 || a.n_steps == 0) return DDD_OK;
   m->last_batch = a.batch;
-  m->last_launch_streamed = false;
+  m->last_launch_streamed = false; m->last_launch_lean = false;
 #ifdef DDD_PROBES   // profiling knobs (ddd_debug_set_option; profiles/r1_ablation.txt)
   a.prio_split = g_debug.prio_split;
   a.stagger = g_debug.stagger;
@@ -960,6 +1014,14 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   a.ablate = g_debug.ablate;
 #endif
   m->last_launch_split = false;
+  if (m->kernel == DDD_KERNEL_MFMA && std::is_same<ST, float>::value && !m->explicit_kernel &&
+      !g_debug.no_lean && launch_lean(m, a, stream)) {
+    // fixed stencils / one-layer nets, float32 state, whole samples per wavefront: the
+    // lane == grid point kernel (no matrix work to schedule around)
+    m->last_launch_lean = true;
+    DDD_HIP(hipGetLastError());
+    return DDD_OK;
+  }
   if (m->kernel == DDD_KERNEL_MFMA) {
     MfmaGeometry geo = mfma_geometry(m, a.batch);
     if (geo.rows == 64 && geo.wave_rows == 64 && std::is_same<ST, float>::value &&
@@ -1643,6 +1705,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   if (launch_mode == DDD_LAUNCH_PERSISTENT) {
     ddd::IntegrateArgs a{};
     a.t0 = t0; a.dt = dt; a.n_steps = n_steps; a.save_every = save_every; a.tab = tab;
+    a.sc = make_stage_consts(tab, dt);
     a.y0 = y0; a.y_out = y_out; a.batch = batch;
     return launch_integrate<float>(m, a, stream);
   }
@@ -1658,6 +1721,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   float* pong = m->d_scratch + elems;
   float* ystage = m->d_scratch + 2 * elems;
   const float h = (float)dt;
+  const ddd::StageConsts stage_consts = make_stage_consts(tab, dt);
 
   // large ensembles: two half-ensembles side by side (plan_slabs)
   const SlabPlan plan = plan_slabs(m, batch);
@@ -1685,7 +1749,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
       const bool saving = (step + 1) % save_every == 0;
       float* ynew = saving ? y_out + snap * elems : (y == ping ? pong : ping);
       ddd::StepArgs sa{};
-      sa.t = t0 + (double)step * dt; sa.dt = dt; sa.tab = tab;
+      sa.t = t0 + (double)step * dt; sa.dt = dt; sa.tab = tab; sa.sc = stage_consts;
       sa.y_in = y; sa.y_out = ynew; sa.batch = batch;
       ddd::stream::launch_fixed_step(dim3(grid), stream, m->dp, sa, tiles);
       y = ynew;
@@ -1693,7 +1757,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
     }
     DDD_HIP(hipGetLastError());
     m->last_batch = batch;
-    m->last_launch_streamed = true;
+    m->last_launch_streamed = true; m->last_launch_lean = false;
     return DDD_OK;
   }
   hipStream_t lanes[kMaxParts] = {stream, stream, stream, stream};
@@ -1727,7 +1791,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
           dp.runs += (size_t)slab_first[hf] * 8;
         }
         ddd::StepArgs sa{};
-        sa.t = t; sa.dt = dt; sa.tab = tab;
+        sa.t = t; sa.dt = dt; sa.tab = tab; sa.sc = stage_consts;
         sa.y_in = y + half_off[hf]; sa.y_out = ynew + half_off[hf]; sa.batch = half_batch[hf];
         const int groups = (half_batch[hf] + spg - 1) / spg;
         const int grid = std::min(groups, capacity);
@@ -1745,7 +1809,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
         rc = fail(DDD_ERR_HIP, "step launch failed");
         break;
       }
-      m->last_launch_streamed = false;
+      m->last_launch_streamed = false; m->last_launch_lean = false;
       y = ynew;
       if (saving) ++snap;
       continue;
@@ -1847,6 +1911,7 @@ int ddd_integrate_fixed_f64(ddd_model* m, int scheme, double t0, double dt, int 
   rc = make_tableau(scheme, &a.tab);
   if (rc) return rc;
   a.t0 = t0; a.dt = dt; a.n_steps = n_steps; a.save_every = save_every;
+  a.sc = make_stage_consts(a.tab, dt);
   a.y0 = y0; a.y_out = y_out; a.batch = batch;
   return launch_integrate<double>(m, a, static_cast<hipStream_t>(stream));
 }
@@ -1918,7 +1983,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   }
   a.max_attempts = max_attempts;
   m->last_batch = batch;
-  m->last_launch_streamed = false;
+  m->last_launch_streamed = false; m->last_launch_lean = false;
   m->last_launch_split = false;
   if (m->spectral) {
     // float64 right-hand side (SpectralDifferentiator), one workgroup per sample
@@ -2143,6 +2208,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m == nullptr) return "";
   if (m->spectral) return "spectral_f64";
   if (m->last_launch_streamed) return "stream_fixed";
+  if (m->last_launch_lean) return "valu_f32_lean";
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
@@ -2162,6 +2228,7 @@ DDD_API int ddd_debug_set_option(const char* name, long long value) {
   if (key == "no_fold") g_debug.no_fold = (int)value;
   else if (key == "no_spec") g_debug.no_spec = (int)value;
   else if (key == "no_stream") g_debug.no_stream = (int)value;
+  else if (key == "no_lean") g_debug.no_lean = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;
   else if (key == "substep_parts") g_debug.substep_parts = (int)value;
@@ -2312,6 +2379,42 @@ int ddd_selftest_mfma_layout(void) {
                         "mfma_f32_4x4x1 broadcast layout mismatch at abid %d reg %d lane %d: "
                         "got %g want %g", abid, r, l, got, want);
         }
+  }
+  {
+    // relu as the [0, 1] output clamp of a packed add on activations scaled by
+    // 2^-kReluShift (rhs_mfma.h: activate16), and the constant-lane-mask select of the
+    // input layer (upper_half_one)
+    std::vector<float> h_in(128);
+    const float dn = std::ldexp(1.0f, -ddd::kReluShift);
+    for (int i = 0; i < 128; ++i) {
+      const float mag = std::ldexp(1.0f + 0.0078125f * (float)i, (i * 7) % 120 - 60);   // 2^-60 .. 2^59
+      h_in[i] = ((i % 3) == 1 ? -mag : mag) * dn;
+    }
+    h_in[5] = 0.0f; h_in[6] = -0.0f; h_in[7] = std::nanf(""); h_in[8] = 2.0f;   // (> 1: saturates)
+    h_in[9] = -INFINITY; h_in[10] = INFINITY; h_in[11] = 1.0f;
+    float *d_in = nullptr, *d_out = nullptr;
+    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d_in), 128 * sizeof(float)));
+    DDD_HIP(hipMalloc(reinterpret_cast<void**>(&d_out), 192 * sizeof(float)));
+    DDD_HIP(hipMemcpy(d_in, h_in.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ddd::ops::relu_clamp_probe_kernel, dim3(1), dim3(64), 0, nullptr, d_in, d_out);
+    DDD_HIP(hipGetLastError());
+    std::vector<float> h_out(192);
+    DDD_HIP(hipMemcpy(h_out.data(), d_out, 192 * sizeof(float), hipMemcpyDeviceToHost));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    for (int l = 0; l < 64; ++l)
+      for (int e = 0; e < 2; ++e) {
+        const float x = h_in[2 * l + e], got = h_out[64 * e + l];
+        const float want = std::isnan(x) ? 0.0f : x < 0.0f ? 0.0f : x > 1.0f ? 1.0f : x;
+        if (!(got == want) || std::signbit(got))
+          return fail(DDD_ERR_UNSUPPORTED,
+                      "v_pk_add_f32 ... clamp is not the [0, 1] clamp the relu assumes: "
+                      "input %g (element %d of pair %d) gave %g, want %g", x, e, l, got, want);
+      }
+    for (int l = 0; l < 64; ++l)
+      if (h_out[128 + l] != (l < 32 ? (float)l : 1.0f))
+        return fail(DDD_ERR_UNSUPPORTED, "constant-lane-mask select: lane %d gave %g", l,
+                    h_out[128 + l]);
   }
   // informational: the kernels fall back to ds_bpermute when this is 0
   (void)dpp_wave_rol_ok();

@@ -18,6 +18,20 @@ constexpr int kTraceSlots = 256;
 constexpr int kWalkTraceRows = 2048;   // rows per launch of the substep-walk trace (probe library)
 constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
 
+// relu on the MFMA path = the VALU's [0, 1] output clamp on a PACKED add (v_pk_add_f32 x, 0
+// clamp: two accumulator registers per instruction; gfx950 has no packed f32 max), on
+// activations the host scaled by 2^-kReluShift: the input layer's weights and every
+// bias row of the tower carry the factor, the output layer's weights carry its inverse
+// (capi.hip: pack_mfma_weights).  Powers of two commute with every rounding of the fma
+// chains, so the finite results are the bits of max(x, 0) for activations in
+// [2^(-126 + kReluShift), 2^kReluShift] -- beyond 1.8e19 a state has diverged, below
+// 2e-19 an activation contributes nothing float32 can see.  NaN -> 0 like v_max (DX10 clamp).
+// 64 relu instructions per wave-evaluation become 32 (profiles/r5_valu_census.txt).
+#ifndef DDD_RELU_CLAMP
+#define DDD_RELU_CLAMP 1   // A/B (profiles/r5_ablation.txt): 0 = one v_max_f32 per element, unscaled weights
+#endif
+constexpr int kReluShift = DDD_RELU_CLAMP ? 64 : 0;
+
 // Equation ids: include/ddd1d.h enum ddd_equation.
 enum : int {
   EQ_BURGERS = 0, EQ_BURGERS_CONS = 1, EQ_KDV = 2, EQ_KDV_CONS = 3,
@@ -40,8 +54,10 @@ struct DevParams {
   // model
   int fixed;           // 1: fixed stencils in `bias` ([D][G]); no conv net
   int weno;            // fixed only: derivatives 0 / 1 are WENO5 reconstructions
-  // One-layer nets (num_layers = 1: the model of the reference's own integration tests,
-  // integrate_test.py:48): the coefficients are AFFINE in the K neighbouring values,
+  // One-layer nets (num_layers = 1, a hyper-parameter training.create_hparams admits;
+  // integrate_test.py:48 names it in `model_kwargs` but never passes it -- the reference's
+  // tests train the default three-layer net): the coefficients are AFFINE in the K
+  // neighbouring values,
   //   coeff[d][g] = B[d][g] + sum_k M[k][d][g] (u / std)[x + k - K/2],
   // with B / M folded on the host (float64) from the conv layer, the null space and the
   // accuracy bias.  linear_taps = K > 0: the MFMA-path kernels skip the tower like a fixed
@@ -110,10 +126,23 @@ struct Tableau {
   double c[kMaxStages];
 };
 
+// Per-stage constants of one fixed-step launch, formed ONCE on the host in the kernels' own
+// arithmetic (capi.hip: make_stage_consts) and carried in the kernel-argument segment:
+// indexed by the stage inside the time loop they were three scalar loads with their
+// waits and four float / float64 multiplies per evaluation; here they are SGPRs picked
+// by scalar selects.
+struct StageConsts {
+  float ah[kMaxStages], bh[kMaxStages];      // float state:   a[s] * (float)dt, b[s] * (float)dt
+  double ahd[kMaxStages], bhd[kMaxStages];   // float64 state: (double)a[s] * dt, (double)b[s] * dt
+  double ct[kMaxStages];                     // c[s] * dt
+  int b_nonzero;                             // bit s: b[s] != 0 (stage s enters the update)
+};
+
 struct IntegrateArgs {
   double t0, dt;
   int n_steps, save_every;
   Tableau tab;
+  StageConsts sc;
   const void* y0;   // [batch][N] StateT
   void* y_out;      // [n_saved][batch][N] StateT
   int batch;
@@ -142,6 +171,7 @@ struct AdaptiveArgs {
 struct StepArgs {
   double t, dt;
   Tableau tab;
+  StageConsts sc;
   const float* y_in;
   float* y_out;
   int batch;

@@ -206,5 +206,21 @@ __global__ void mfma4_layout_probe_kernel(float* __restrict__ out) {   // [16][4
 #undef DDD_P4
 }
 
+// What the relu of the MFMA path assumes of `v_pk_add_f32 x, 0 clamp` (rhs_mfma.h:
+// activate16) and of the constant-lane-mask select (upper_half_one): out[0][i] / out[1][i]
+// = the clamped pair built from in[2 i], in[2 i + 1]; out[2][lane] = the select of the lane id.
+__global__ void relu_clamp_probe_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int l = threadIdx.x;
+  f32x2 v{in[2 * l], in[2 * l + 1]}, y;
+  asm volatile("v_pk_add_f32 %0, %1, 0 clamp" : "=v"(y) : "v"(v));
+  out[l] = y[0];
+  out[64 + l] = y[1];
+  float sel;
+  const float x = (float)l;
+  asm volatile("v_cndmask_b32_e64 %0, %1, 1.0, %2" : "=v"(sel) : "v"(x), "s"(0xffffffff00000000ull));
+  out[128 + l] = sel;
+}
+
 }  // namespace ops
 }  // namespace ddd

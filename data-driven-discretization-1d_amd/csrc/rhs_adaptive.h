@@ -132,10 +132,19 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   const double interval = fabs(t_bound - t0);
   const double rtol = a.rtol, atol = a.atol, max_step = a.max_step;
   const double sqrt_n = sqrt((double)p.N);   // _ivp.common.norm: ||x|| / x.size ** 0.5
+  // N a power of four (16, 64, 256): x.size ** 0.5 is a power of two and the division is
+  // an exact multiplication -- a dozen float64 instructions less per error norm
+  const bool sqrt_n_pow2 = (p.N & (p.N - 1)) == 0 && (__builtin_ctz(p.N) & 1) == 0;
+  const double inv_sqrt_n = 1.0 / sqrt_n;
   const size_t row_stride = (size_t)a.batch * p.N;
   const auto rms = [&](double q) {
-    return sqrt(sample_sum<kRows, kWR>(p, ln, q * q, red)) / sqrt_n;
+    const double nrm = sqrt(sample_sum<kRows, kWR>(p, ln, q * q, red));
+    return sqrt_n_pow2 ? nrm * inv_sqrt_n : nrm / sqrt_n;
   };
+  // forcing sums computed outside an evaluation (the first stage of every attempt): the
+  // masked first trip of forcing_phase2 where the evaluation keeps the masks resident anyway
+  constexpr bool kMaskedSums = kHoist && kWR == 64 && kEq >= 0 && !adaptive_lean<kRows>() &&
+                               spec_folded(kEq >= 0 ? kEq : 0);
 
   // The step-size controllers live in LDS, one per sample of the group: their 7
   // doubles + 4 ints are identical on all lanes of a sample and are touched once
@@ -202,7 +211,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
         else if (phase == 3) { ft_now = ft + 0.75 * fh; ft_next = ft + fh; }
         else if (phase == 4) { ft_now = ft + fh; ft_next = ft_now; }
       }
-      if (!sums_ready) res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)ft_now, tid);
+      if (!sums_ready)
+        res.fk_next = forcing_sums<kRows, kWR, kMaskedSums>(p, sm, res, (float)ft_now, tid);
       tn_lane = (float)ft_next;
     }
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>(), TW>(

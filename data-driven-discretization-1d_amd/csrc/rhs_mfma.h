@@ -51,6 +51,7 @@ __host__ __device__ constexpr int tab_rows(bool wide) { return 4 + flavour_chann
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Geometry of the conv tower a kernel instantiation carries: kK taps, kCB blocks of
 // 32 hidden channels.  Tower<5, 1> is the reference's default net (training.py:134-136)
@@ -221,6 +222,46 @@ __host__ __device__ constexpr int rt_head_groups(int groups) {
   return groups % 2 == 0 ? 0 : groups == 1 ? 1 : 3;
 }
 
+// Entry `s` of a per-stage constant array that sits in the kernel-argument segment
+// (StageConsts): scalar compares + selects on SGPRs instead of an indexed scalar LOAD
+// (and its wait) inside the time loop.
+// (written as scalar compare + select instructions: as C++ selects the compiler turns the
+// four kernel-argument loads back into ONE load at a selected offset, or -- through
+// opaque copies -- into branches or a scratch array, all of which stall the wavefront.)
+__device__ __forceinline__ float pick4(int s, float v0, float v1, float v2, float v3) {
+  float r;
+  asm("s_cmp_eq_u32 %1, 1\n\ts_cselect_b32 %0, %3, %2\n\t"
+      "s_cmp_eq_u32 %1, 2\n\ts_cselect_b32 %0, %4, %0\n\t"
+      "s_cmp_eq_u32 %1, 3\n\ts_cselect_b32 %0, %5, %0"
+      : "=&s"(r) : "s"(s), "s"(v0), "s"(v1), "s"(v2), "s"(v3) : "scc");
+  return r;
+}
+__device__ __forceinline__ double pick4(int s, double v0, double v1, double v2, double v3) {
+  double r;
+  asm("s_cmp_eq_u32 %1, 1\n\ts_cselect_b64 %0, %3, %2\n\t"
+      "s_cmp_eq_u32 %1, 2\n\ts_cselect_b64 %0, %4, %0\n\t"
+      "s_cmp_eq_u32 %1, 3\n\ts_cselect_b64 %0, %5, %0"
+      : "=&s"(r) : "s"(s), "s"(v0), "s"(v1), "s"(v2), "s"(v3) : "scc");
+  return r;
+}
+template <typename T>
+struct StagePick {
+  const T (&v)[kMaxStages];
+  __device__ __forceinline__ explicit StagePick(const T (&v_)[kMaxStages]) : v(v_) {}
+  __device__ __forceinline__ T at(int s) const { return pick4(s, v[0], v[1], v[2], v[3]); }
+};
+// a[s] h and b[s] h in the state's type
+template <typename ST>
+__device__ __forceinline__ StagePick<ST> stage_ah(const StageConsts& sc) {
+  if constexpr (sizeof(ST) == 4) return StagePick<ST>(sc.ah);
+  else return StagePick<ST>(sc.ahd);
+}
+template <typename ST>
+__device__ __forceinline__ StagePick<ST> stage_bh(const StageConsts& sc) {
+  if constexpr (sizeof(ST) == 4) return StagePick<ST>(sc.bh);
+  else return StagePick<ST>(sc.bhd);
+}
+
 struct Lane {
   int row;       // row inside the workgroup this lane owns in VALU phases
   int base;      // first row of the row's sample
@@ -354,6 +395,21 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
   if (act == ACT_RELU) {
+#if DDD_RELU_CLAMP
+    // TWO elements per instruction: the [0, 1] output clamp of a packed add of zero, on
+    // activations that carry the factor 2^-kReluShift (dev_params.h; the host packs the
+    // weights accordingly) -- gfx950 has no packed f32 max, and every VALU instruction
+    // of a layer boundary is time the matrix pipe stands still.  clamp(NaN) = 0 (DX10
+    // clamp mode, the HSA default), like v_max_f32 0, NaN.  The inline constant 0 is 0 in
+    // both halves whatever the operand's op_sel semantics.
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 v{acc[r], acc[r + 1]}, y;
+      asm("v_pk_add_f32 %0, %1, 0 clamp" : "=v"(y) : "v"(v));
+      acc[r] = y[0];
+      acc[r + 1] = y[1];
+    }
+#else
     // ONE v_max_f32 per element.  fmaxf / fmed3 builtins make the compiler
     // prepend a canonicalising v_max x, x (it cannot prove an MFMA result is
     // not a signalling NaN), doubling the VALU work of every layer boundary,
@@ -364,6 +420,7 @@ __device__ __forceinline__ void activate16(f32x16& acc, int act) {
       asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(acc[r]));
       acc[r] = y;
     }
+#endif
   } else if (act == ACT_RELU6) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
@@ -390,6 +447,26 @@ __device__ __forceinline__ void store_tile32(float* out, int trow, int half,
         acc[4 * qd + 0], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
 }
 
+// The same with the row's LDS byte offset ((row * kHS + 4 half) * 4) already formed
+// (Resident::st_off: lane == row never changes inside a launch).
+__device__ __forceinline__ void store_tile32_at_bytes(float* out, int byte_off, const f32x16& acc) {
+  char* orow = reinterpret_cast<char*>(out) + byte_off;
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd)
+    *reinterpret_cast<float4*>(orow + 32 * qd) = make_float4(
+        acc[4 * qd + 0], acc[4 * qd + 1], acc[4 * qd + 2], acc[4 * qd + 3]);
+}
+
+// x on lanes 0..31, 1.0 on lanes 32..63 (the bias row of the input layer's last MFMA
+// step): ONE v_cndmask against a constant lane mask in an SGPR pair instead of
+// and + compare + select on the lane index.
+// (the inverse-ballot builtin, not inline asm: the select feeds an MFMA operand, and the
+// compiler's hazard recognizer does not see VALU instructions hidden in asm statements --
+// an asm v_cndmask here left the MFMA behind it reading a stale register.)
+__device__ __forceinline__ float upper_half_one(float x) {
+  return __builtin_amdgcn_inverse_ballot_w64(0xffffffff00000000ull) ? 1.0f : x;
+}
+
 // Input layer 1 -> 32 for this wave's two 32-row tiles (3 MFMA steps each).
 //   A: lane l supplies W1[out = l & 31][k = 2 s + (l >> 5)]  (k = tap; k = 5: bias)
 //   B: lane l supplies un[(pos(l & 31) + k - 2) mod N], un = u / std   (k = 5: 1.0)
@@ -404,7 +481,7 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
                                             float* __restrict__ out,
                                             const float (&w)[kInSteps],
                                             const int (&rows)[2][kKW], int act,
-                                            const int (*bperm)[3] = nullptr) {
+                                            const int (*bperm)[3] = nullptr, int st_off = 0) {
   constexpr int kT = kWR / 32;
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -431,7 +508,7 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
       b1[t] = kShfl ? __shfl(un, r1, 64) : us[r1];
       b2[t] = kShfl ? __shfl(un, r2, 64) : us[r2];
     }
-    b2[t] = half ? 1.0f : b2[t];
+    b2[t] = kAddr ? upper_half_one(b2[t]) : (half ? 1.0f : b2[t]);
   }
   if (kAddr && kShfl) __builtin_amdgcn_sched_group_barrier(0x080, 3 * kT, 0);   // the permutes first
 #pragma unroll
@@ -448,7 +525,8 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     activate16(acc[t], act);
-    store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
+    if (kAddr) store_tile32_at_bytes(out, st_off + t * 32 * kHS * 4, acc[t]);
+    else store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
 
@@ -465,7 +543,7 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
                                              const float (&w)[kHidSteps],
-                                             const int (&rows)[2][kKW], int act) {
+                                             const int (&rows)[2][kKW], int act, int st_off = 0) {
   constexpr int kT = kWR / 32;   // 32-row tiles of this wave, advanced together
   const int j = ln.lane & 31;
   const int half = ln.lane >> 5;
@@ -519,7 +597,8 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     activate16(acc[t], act);
-    store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
+    if (kByteOffsets) store_tile32_at_bytes(out, st_off + t * 32 * kHS * 4, acc[t]);
+    else store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
 
@@ -828,6 +907,8 @@ struct Resident {
   int in_perm[2][3];        // ds_bpermute addresses of the input layer's operands (same kernels)
   float4 trig[kTrigMax / 4];   // this grid point's cos / sin of the spatial phases (same kernels)
   int pch_idx[kGMax];       // indices into Shared::u of this row's stencil patch (same kernels)
+  int st_off;               // LDS byte offset of this lane's tile-0 activation row (+ 16 half; same kernels)
+  int fk_off;               // byte offset of this row's sample in Shared::fk (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
@@ -1013,7 +1094,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // differ in its last bit.  Every VALU instruction here is matrix-pipe time.
   const float q_un = u * p.inv_stddev;
   float un_reg = fmaf(fmaf(-q_un, p.stddev, u), p.inv_stddev, q_un);
-  if (p.exact_div) un_reg = u / p.stddev;   // wave-uniform
+  if (p.exact_div) {   // wave-uniform, and a BRANCH: as a select, the 12-instruction IEEE
+    asm volatile("; exact division");   // sequence ran in every evaluation (round 4: 14 of 182)
+    un_reg = u / p.stddev;
+  }
   // (a one-wave group feeds the input layer by lane permutes, not through LDS)
   if (!fixed && !kOneWave && ln.owner) sm.un[ln.row] = un_reg;
   // harmonic forcing sums of THIS evaluation's time: computed during the
@@ -1048,7 +1132,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       input_layer_big<TW, kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, hid_rows, act);
     } else if (!(ablate & 16)) {
       input_layer<kWR, kOneWave, kKeepOffsets>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows,
-                                               act, res.in_perm);
+                                               act, res.in_perm, res.st_off);
     }
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
     if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
@@ -1061,7 +1145,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       } else {
         if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
         group_barrier<kRows, kWR>();
-        hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act);
+        hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
       }
       float* tmp = in; in = out; out = tmp;
     }
@@ -1278,11 +1362,17 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                : pow2 ? (((ln.pos + g - gl) & (p.N - 1)) | ln.base)
                                       : wrap_row(ln.base, ln.pos, g - gl, p.N)] : 0.0f;
   }
-  float cf[kMaxDerivs][kGW];
+  // coefficients as register PAIRS: the projection and the bias add run on packed FMAs /
+  // adds (two stencil columns per instruction, each column's fma chain unchanged -- the
+  // same bits); left to the SLP vectoriser the unfolded kernels spent more v_mov than FMA
+  // instructions shuffling pairs together (round 4: 84 v_mov_b32 per evaluation in the
+  // non-flux Burgers kernel).  CF(d, g) is the scalar view.
+  f32x2 cf2[kMaxDerivs][kGW / 2];
+#define CF(d, g) cf2[d][(g) >> 1][(g) & 1]
 #pragma unroll
   for (int d = 0; d < kMaxDerivs; ++d)
 #pragma unroll
-    for (int g = 0; g < kGW; ++g) cf[d][g] = 0.0f;
+    for (int q = 0; q < kGW / 2; ++q) cf2[d][q] = f32x2{0.0f, 0.0f};
   if (!fixed && folded && !kWide) {
     // the output layer already applied the projection (or the net emits the
     // coefficients themselves, polynomial_accuracy_order 0): channel G d + g,
@@ -1291,16 +1381,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     if (kSpec) {
 #pragma unroll
       for (int g = 0; g < kGW; ++g)
-        if (g < nG) { cf[0][g] = net[g]; cf[1][g] = net[nG + g]; }
+        if (g < nG) { CF(0, g) = net[g]; CF(1, g) = net[nG + g]; }
     } else if (nG == 6) {
 #pragma unroll
-      for (int g = 0; g < 6; ++g) { cf[0][g] = net[g]; cf[1][g] = net[6 + g]; }
+      for (int g = 0; g < 6; ++g) { CF(0, g) = net[g]; CF(1, g) = net[6 + g]; }
     } else if (nG == 7) {
 #pragma unroll
-      for (int g = 0; g < 7; ++g) { cf[0][g] = net[g]; cf[1][g] = net[7 + g]; }
+      for (int g = 0; g < 7; ++g) { CF(0, g) = net[g]; CF(1, g) = net[7 + g]; }
     } else {
 #pragma unroll
-      for (int g = 0; g < 8; ++g) { cf[0][g] = net[g]; cf[1][g] = net[8 + g]; }
+      for (int g = 0; g < 8; ++g) { CF(0, g) = net[g]; CF(1, g) = net[8 + g]; }
     }
   } else if (!fixed && !(ablate & 2)) {
 #pragma unroll
@@ -1311,26 +1401,30 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       if (kSpec ? c >= spec_net_channels(kSpec ? kEq : 0) : !((dsel_valid >> c) & 1u)) continue;
       const unsigned d = kSpec ? (unsigned)spec_channel_deriv(kSpec ? kEq : 0, c)
                                : (unsigned)(dsel_bits >> (2 * c)) & 3u;
-      const float nv = net[c];
-      float nsr[kGW];
+      const f32x2 nv2{net[c], net[c]};
+      f32x2 nsr[kGW / 2];   // the channel's null-space row (zero beyond the stencil: fma(nv, 0, 0) = 0)
 #pragma unroll
       for (int q4 = 0; q4 < kGW / 4; ++q4) {
         const float4 nq = *reinterpret_cast<const float4*>(sm.tab + (4 + c) * kGW + 4 * q4);
-        nsr[4 * q4 + 0] = nq.x; nsr[4 * q4 + 1] = nq.y;
-        nsr[4 * q4 + 2] = nq.z; nsr[4 * q4 + 3] = nq.w;
+        nsr[2 * q4] = f32x2{nq.x, nq.y};
+        nsr[2 * q4 + 1] = f32x2{nq.z, nq.w};
       }
+      // (kSpec: pairs past the stencil are skipped at compile time)
       if (d == 0) {
 #pragma unroll
-        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[0][g] = fmaf(nv, nsr[g], cf[0][g]);
+        for (int q = 0; q < kGW / 2; ++q)
+          if (!kSpec || 2 * q < nG) cf2[0][q] = __builtin_elementwise_fma(nv2, nsr[q], cf2[0][q]);
       } else if (d == 1) {
 #pragma unroll
-        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[1][g] = fmaf(nv, nsr[g], cf[1][g]);
+        for (int q = 0; q < kGW / 2; ++q)
+          if (!kSpec || 2 * q < nG) cf2[1][q] = __builtin_elementwise_fma(nv2, nsr[q], cf2[1][q]);
       } else if (d == 2) {
 #pragma unroll
-        for (int g = 0; g < kGW; ++g) if (!kSpec || g < nG) cf[2][g] = fmaf(nv, nsr[g], cf[2][g]);
+        for (int q = 0; q < kGW / 2; ++q)
+          if (!kSpec || 2 * q < nG) cf2[2][q] = __builtin_elementwise_fma(nv2, nsr[q], cf2[2][q]);
       } else {
 #pragma unroll
-        for (int g = 0; g < kGW; ++g) cf[3][g] = fmaf(nv, nsr[g], cf[3][g]);
+        for (int q = 0; q < kGW / 2; ++q) cf2[3][q] = __builtin_elementwise_fma(nv2, nsr[q], cf2[3][q]);
       }
     }
   }
@@ -1344,17 +1438,18 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                    : wrap_row(ln.base, ln.pos, k - left, p.N)];
         const float qk = uk * p.inv_stddev;
         float unk = fmaf(fmaf(-qk, p.stddev, uk), p.inv_stddev, qk);   // u / std, as in the tower
-        if (p.exact_div) unk = uk / p.stddev;
+        if (p.exact_div) { asm volatile("; exact division"); unk = uk / p.stddev; }
 #pragma unroll
         for (int d = 0; d < kMaxDerivs - 1; ++d) {
           if (d >= nD) continue;
           const float* __restrict__ row = sm.tab + (4 + k * nD + d) * kGW;
           const float4 m0 = *reinterpret_cast<const float4*>(row);
           const float4 m1 = *reinterpret_cast<const float4*>(row + 4);
-          cf[d][0] = fmaf(unk, m0.x, cf[d][0]); cf[d][1] = fmaf(unk, m0.y, cf[d][1]);
-          cf[d][2] = fmaf(unk, m0.z, cf[d][2]); cf[d][3] = fmaf(unk, m0.w, cf[d][3]);
-          cf[d][4] = fmaf(unk, m1.x, cf[d][4]); cf[d][5] = fmaf(unk, m1.y, cf[d][5]);
-          cf[d][6] = fmaf(unk, m1.z, cf[d][6]); cf[d][7] = fmaf(unk, m1.w, cf[d][7]);
+          const f32x2 u2{unk, unk};
+          cf2[d][0] = __builtin_elementwise_fma(u2, f32x2{m0.x, m0.y}, cf2[d][0]);
+          cf2[d][1] = __builtin_elementwise_fma(u2, f32x2{m0.z, m0.w}, cf2[d][1]);
+          cf2[d][2] = __builtin_elementwise_fma(u2, f32x2{m1.x, m1.y}, cf2[d][2]);
+          cf2[d][3] = __builtin_elementwise_fma(u2, f32x2{m1.z, m1.w}, cf2[d][3]);
         }
       }
       // four-wave groups: a faster wavefront rewrites sm.u as soon as it enters the next
@@ -1370,10 +1465,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       if (d >= nD) continue;
       float mean = 0.0f;
 #pragma unroll
-      for (int g = 0; g < kGW; ++g) if (g < nG) mean += cf[d][g];
+      for (int g = 0; g < kGW; ++g) if (g < nG) mean += CF(d, g);
       mean = mean / (float)nG;
 #pragma unroll
-      for (int g = 0; g < kGW; ++g) if (g < nG) cf[d][g] = cf[d][g] - mean;
+      for (int g = 0; g < kGW; ++g) if (g < nG) CF(d, g) = CF(d, g) - mean;
     }
   }
   float dv[kMaxDerivs];
@@ -1385,18 +1480,30 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
         dv[d] = net[d];
         continue;
       }
+      if (!folded || kWide) {   // (folded: the bias rides in the output layer's bias row)
 #pragma unroll
-      for (int g = 0; g < kGW; ++g)   // folded: the bias rides in the output layer's bias row
-        if (!folded || kWide) cf[d][g] = sm.tab[d * kGW + g] + cf[d][g];
+        for (int q = 0; q < kGW / 2; ++q) {
+          const float2 bq = *reinterpret_cast<const float2*>(sm.tab + d * kGW + 2 * q);
+          cf2[d][q] = f32x2{bq.x, bq.y} + cf2[d][q];
+        }
+      }
       if (coeffs_out != nullptr && ln.active) {
         float* dst = coeffs_out + ((size_t)ln.gidx * nD + d) * nG;
 #pragma unroll
-        for (int g = 0; g < kGW; ++g) if (g < nG) dst[g] = cf[d][g];
+        for (int g = 0; g < kGW; ++g) if (g < nG) dst[g] = CF(d, g);
       }
+      // (one scalar chain per derivative, in stencil order -- the order of the streaming
+      // kernel and the oracle.  The empty asm after every link keeps the SLP vectoriser
+      // from pairing the derivatives' chains into packed FMAs: it paid two v_mov per pair
+      // to build their operands.  It emits nothing, so the FMAs stay visible to the hazard
+      // recognizer -- their operands come straight from the output layer's MFMAs.)
       float s = 0.0f;
 #pragma unroll
       for (int g = 0; g < kGW; ++g)
-        if (!kSpec || g < nG) s = fmaf(cf[d][g], pch[g], s);   // padded columns: cf = 0
+        if (!kSpec || g < nG) {   // padded columns: cf = 0
+          s = fmaf(CF(d, g), pch[g], s);
+          asm("" : "+v"(s));
+        }
       dv[d] = s;
     }
   }
@@ -1437,7 +1544,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // phase 3: combine with this grid point's cos / sin table (both zero
       // padded to 12 entries: no branches)
       const float4* __restrict__ fk4 =
-          reinterpret_cast<const float4*>(sm.fk + ln.sl * kTrigMax);
+          kKeepOffsets ? reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sm.fk) + res.fk_off)
+                       : reinterpret_cast<const float4*>(sm.fk + ln.sl * kTrigMax);
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
@@ -1455,6 +1563,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   }
   DDD_STAMP(4);
 #undef DDD_STAMP
+#undef CF
   return r;
 }
 
@@ -1496,6 +1605,8 @@ __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln,
     res.in_perm[t2][1] = opaque(4 * (half ? rows[3] : rows[2]));
     res.in_perm[t2][2] = opaque(4 * rows[4]);
   }
+  res.st_off = opaque((int)__umul24((unsigned)(ln.wave * kWR + (ln.lane & 31)), (unsigned)(kHS * 4)) +
+                      16 * half);
   const int gl = p.G >> 1;
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;
 #pragma unroll
@@ -1563,6 +1674,8 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     res.frc_slot = (fast && tid < spg * p.n_k * 2)
                        ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
   }
+  res.fk_off = opaque(ln.sl * kTrigMax * 4);   // (fixed-stencil models with forcing read it too)
+  res.st_off = 0;
   if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || p.w_final4_split != nullptr))
     lane_offsets<kRows, kWR>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
@@ -1821,8 +1934,9 @@ __device__ __forceinline__ void step_walk(const DevParams& p, const StepArgs& a,
   const SampleSetup s_first = fetch_samples<kRows, kWR>(p, first, a.batch, fast_frc);
   setup_weights<kRows, kWR, true>(p, sm, ln, res);
   apply_samples<kRows, kWR>(sm, res, s_first);
-  const float h = (float)a.dt;
-  const float t_first = (float)(a.t + a.tab.c[0] * a.dt);
+  const StagePick<float> ah(a.sc.ah), bh(a.sc.bh);
+  const StagePick<double> ct(a.sc.ct);
+  const float t_first = (float)(a.t + ct.at(0));
   if (fast_frc) res.fk_next = forcing_sums<kRows, kWR, true>(p, sm, res, t_first, tid);
   for (int grp = first; grp < groups; grp += stride) {
     const int nxt = grp + stride;
@@ -1838,16 +1952,16 @@ __device__ __forceinline__ void step_walk(const DevParams& p, const StepArgs& a,
     const float y = u;
     float ynew = y, kprev = 0.0f;
     for (int s = 0; s < a.tab.stages; ++s) {
-      const float us = s > 0 ? y + kprev * (a.tab.a[s] * h) : y;
+      const float us = s > 0 ? y + kprev * ah.at(s) : y;
       const bool last = s + 1 == a.tab.stages;
       // sums prepared inside this evaluation: this group's next stage, or -- in
       // its last stage -- the NEXT group's first stage (other samples, same step)
       if (last && more) apply_samples<kRows, kWR, false>(sm, res, s_next);
-      const float tn = last ? t_first : (float)(a.t + a.tab.c[s + 1] * a.dt);
+      const float tn = last ? t_first : (float)(a.t + ct.at(s + 1));
       const float f = eval_rhs<kRows, kWR, true, kEq, false>(
-          p, sm, a.batch, us, (float)(a.t + a.tab.c[s] * a.dt), tn, res, fast_frc, nullptr,
+          p, sm, a.batch, us, (float)(a.t + ct.at(s)), tn, res, fast_frc, nullptr,
           nullptr, !last || more, grp);
-      if (a.tab.b[s] != 0.0f) ynew = ynew + (a.tab.b[s] * h) * f;
+      if ((a.sc.b_nonzero >> s) & 1) ynew = ynew + bh.at(s) * f;
       kprev = f;
     }
     if (ln.active) a.y_out[ln.gidx] = ynew;
@@ -1925,26 +2039,31 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   if (fast_frc && !(ablate & 1))
     res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
                                                   (int)threadIdx.x);
+  // (the per-stage products a[s] h, b[s] h, c[s] dt: StageConsts, formed on the host in this
+  // arithmetic -- (ST)a[s] * (ST)dt etc. -- and picked by scalar selects)
+  (void)h;
+  const StagePick<ST> ah = stage_ah<ST>(a.sc), bh = stage_bh<ST>(a.sc);
+  const StagePick<double> ct(a.sc.ct);
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
+    const double t_after = a.t0 + (double)(step + 1) * a.dt;
     ST ynew = y;
     float kprev = 0.0f;
     for (int s = 0; s < a.tab.stages; ++s) {
       ST us = y;
-      if (s > 0) us = y + (ST)kprev * ((ST)a.tab.a[s] * h);
+      if (s > 0) us = y + (ST)kprev * ah.at(s);
       unsigned long long* tr = nullptr;
       if (kTrace && trace_base != nullptr && evals * 5 + 5 <= kTraceSlots)
         tr = trace_base + (size_t)(int)blockIdx.x * kTraceSlots + evals * 5;
       ++evals;
       // time of the evaluation after this one (next stage, or stage 0 of the
       // next step): its forcing sums are prepared inside this evaluation
-      const double tn = s + 1 < a.tab.stages
-                            ? t + a.tab.c[s + 1] * a.dt
-                            : (a.t0 + (double)(step + 1) * a.dt) + a.tab.c[0] * a.dt;
+      const bool last = s + 1 == a.tab.stages;
+      const double tn = (last ? t_after : t) + ct.at(last ? 0 : s + 1);
       const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(
-          p, sm, a.batch, (float)us, (float)(t + a.tab.c[s] * a.dt), (float)tn, res, fast_frc,
+          p, sm, a.batch, (float)us, (float)(t + ct.at(s)), (float)tn, res, fast_frc,
           nullptr, nullptr, true, -1, ablate, tr);
-      if (a.tab.b[s] != 0.0f) ynew = ynew + ((ST)a.tab.b[s] * h) * (ST)f;
+      if ((a.sc.b_nonzero >> s) & 1) ynew = ynew + bh.at(s) * (ST)f;
       kprev = f;
     }
     y = ynew;

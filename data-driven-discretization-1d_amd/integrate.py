@@ -26,7 +26,7 @@ Results are ``xarray.Dataset`` objects when xarray is importable, otherwise a
 ``Dataset`` stand-in exposing the same ``data_vars`` / ``coords`` mapping.
 """
 import logging
-from typing import Optional, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -510,6 +510,61 @@ def integrate_baseline(equation, times: np.ndarray = _DEFAULT_TIMES,
   return integrate(equation, differentiator, times, warmup,
                    integrate_method=integrate_method,
                    filter_interval=exact_filter_interval)
+
+
+def integrate_baseline_batch(equations, accuracy_orders: Sequence[int] = (1, 3, 5),
+                             times: np.ndarray = _DEFAULT_TIMES, warmup: float = 0,
+                             exact_filter_interval: float = None):
+  """The computational content of ``scripts/create_baseline_data.py:96-130`` on the
+  device: ``integrate_baseline`` (integrate.py:296-308) for every (sample,
+  accuracy order) pair, which the script maps over seeds x ``--accuracy_orders`` one
+  SciPy solve at a time and concatenates along ('sample', 'accuracy_order').
+
+  ``equations``: the coarse (conservative, in the script) equations, same type and
+  grid, one per sample -- they differ by ``random_seed`` (initial condition, forcing).
+  The exact warm-up (``integrate.integrate``: exact solver on the fine grid, optional
+  periodic filtering, then ``grid.resample``) runs ONCE per sample and is shared by
+  all accuracy orders; every order is then one launch of the batched RK23 integrator
+  (one SciPy-identical controller per sample) over its fixed-stencil model, with
+  per-sample forcing for Burgers.  Returns a Dataset with
+  y [sample, accuracy_order, time, x] float32 (the script's ``astype``) and
+  num_evals [sample, accuracy_order].
+  """
+  torch = _lib._torch()
+  equations = list(equations)
+  first = equations[0]
+  for eq in equations[1:]:
+    if type(eq) is not type(first) or (
+        eq.grid.solution_num_points, eq.grid.period, eq.grid.resample_factor) != (
+            first.grid.solution_num_points, first.grid.period, first.grid.resample_factor):
+      raise ValueError('all equations must share their type and grid')
+  times = np.asarray(times, dtype=np.float64)
+  if warmup:
+    warm = integrate_exact_batch(
+        equations, times=np.array([0.0]), warmup=warmup, filter_interval=exact_filter_interval)
+    fine = _dataset_array(warm, 'y')[:, -1]                     # [sample, x_fine] at t = warmup
+    y0 = np.stack([eq.grid.resample(row) for eq, row in zip(equations, fine)])
+  else:
+    y0 = np.stack([eq.initial_value() for eq in equations])
+  y0 = _lib.as_device(y0, torch.float64)
+  forcing = (model_lib.forcing_from_equations(equations)
+             if first.has_time_dependent_forcing else None)
+  ys, evals = [], []
+  for accuracy_order in accuracy_orders:
+    device_model = model_lib.BaselineModel(first, accuracy_order)
+    if forcing is not None:
+      device_model.set_forcing(forcing)
+    y, nfev = _DeviceSolver(device_model).solve(y0, warmup + times)   # [time, sample, x]
+    ys.append(y.permute(1, 0, 2))
+    evals.append(nfev)
+  solution = torch.stack(ys, dim=1).to(torch.float32).cpu().numpy()
+  return _make_dataset(
+      data_vars={'y': (('sample', 'accuracy_order', 'time', 'x'), solution)},
+      coords={'time': warmup + times, 'x': first.grid.solution_x,
+              'sample': np.arange(len(equations)),
+              'accuracy_order': np.asarray(list(accuracy_orders)),
+              'num_evals': (('sample', 'accuracy_order'),
+                            torch.stack(evals, dim=1).cpu().numpy())})
 
 
 def integrate_exact_baseline_and_model(checkpoint_dir: Optional[str],

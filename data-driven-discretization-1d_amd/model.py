@@ -861,6 +861,17 @@ def integrate_ode(model: _DeviceModel, inputs, num_time_steps: int,
   return out.permute(1, 2, 0)
 
 
+def baseline_time_evolution(inputs, num_time_steps: int, equation):
+  """model.py:162-183: time evolution with the baseline model -- fixed polynomial
+  stencils at accuracy order 1, WITHOUT finalize_time_derivative (the reference's
+  ``func`` drops ``t``: no forcing) -- by the midpoint rule with
+  ``equation.time_step``.  Returns [batch, x, num_time_steps] (``integrate_ode`` drops
+  the initial state, model.py:158-159; the reference's docstring says + 1).  One
+  persistent launch of the fixed-stencil kernel for the whole batch."""
+  return integrate_ode(BaselineModel(equation, accuracy_order=1), inputs, num_time_steps,
+                       equation.time_step)
+
+
 def predict_time_evolution(inputs, model: LearnedStencilModel):
   """model.py:643-661 (uses hparams.num_time_steps and equation.time_step).
 

@@ -78,13 +78,22 @@ def store_tile32(buf, trow, half, acc):
       buf[trow, 8 * qd + 4 * half + c] = acc[:, 4 * qd + c]
 
 
-def emulate_tower(un_rows, n, kernels, biases, c_out):
-  """un_rows: [256] already divided by the std.  Returns net [256, 16]."""
+RELU_SHIFT = 64   # dev_params.h: kReluShift
+
+
+def emulate_tower(un_rows, n, kernels, biases, c_out, relu_shift=RELU_SHIFT):
+  """un_rows: [256] already divided by the std.  Returns net [256, 16].
+
+  relu_shift > 0 (the product, dev_params.h kReluShift): activations travel scaled by
+  2^-relu_shift -- input-layer weights and every bias row of the tower carry the factor,
+  the output layer's weights its inverse (capi.hip: pack_mfma_weights) -- and the relu is
+  the VALU's [0, 1] clamp (rhs_mfma.h: activate16); relu_shift = 0: max(x, 0), unscaled."""
   rows_used = (ROWS // n) * n
-  relu = lambda x: np.maximum(x, 0.0)
+  dn, up = np.ldexp(1.0, -relu_shift), np.ldexp(1.0, relu_shift)
+  relu = (lambda x: np.clip(x, 0.0, 1.0)) if relu_shift else (lambda x: np.maximum(x, 0.0))
   hA = np.zeros((ROWS, HS))
   hB = np.zeros((ROWS, HS))
-  w_in = pack_input(kernels[0], biases[0])
+  w_in = pack_input(kernels[0], biases[0]) * dn
   # ---- input layer -------------------------------------------------------
   for wave in range(4):
     j, half = LANES & 31, LANES >> 5
@@ -101,6 +110,7 @@ def emulate_tower(un_rows, n, kernels, biases, c_out):
   # ---- hidden layers -------------------------------------------------------
   for l in range(1, len(kernels) - 1):
     w_h = pack_hidden(kernels[l], biases[l])
+    w_h[80] *= dn   # the bias row
     dst[:] = 0
     for wave in range(4):
       j, half = LANES & 31, LANES >> 5
@@ -117,7 +127,23 @@ def emulate_tower(un_rows, n, kernels, biases, c_out):
         store_tile32(dst, trow, half, relu(acc))
     src, dst = dst, src
   # ---- output layer (run-time-parameterised kernels: 4 padded groups) ---------
-  return emulate_final4(src, n, kernels[-1], biases[-1], c_out, groups=4)
+  return emulate_final4(src, n, kernels[-1] * up, biases[-1], c_out, groups=4)
+
+
+def test_relu_as_scaled_clamp_keeps_the_bits():
+  """float32: x -> 2^64 clamp(2^-64 x, 0, 1) IS max(x, 0) for every activation a
+  finite trajectory produces (|x| in [2^-62, 2^64]); beyond, it saturates / loses
+  subnormal bits -- the documented deviation (dev_params.h: kReluShift)."""
+  rs = np.random.RandomState(0)
+  x = (rs.randn(200000) * np.exp(rs.uniform(-40, 40, 200000))).astype(np.float32)
+  x = x[(np.abs(x) > 2.0 ** -62) & (np.abs(x) < 2.0 ** 63)]
+  dn, up = np.float32(2.0 ** -RELU_SHIFT), np.float32(2.0 ** RELU_SHIFT)
+  got = np.clip(x * dn, np.float32(0), np.float32(1)) * up
+  np.testing.assert_array_equal(got, np.maximum(x, np.float32(0)))
+  # weights: scaling by a power of two commutes with float32 rounding of every product
+  w = rs.randn(1000).astype(np.float32)
+  h = np.abs(rs.randn(1000)).astype(np.float32)
+  np.testing.assert_array_equal((w * up) * (h * dn), w * h)
 
 
 @pytest.mark.parametrize('n,num_layers,c_out', [(64, 3, 9), (32, 3, 11),
@@ -307,10 +333,12 @@ def emulate_big_tower(un_rows, n, kernels, biases, taps, blocks, groups):
   gathers of input_layer_big / hidden_layer_stream / final_layer4<NG, TW>."""
   chans, hs, left = 32 * blocks, 32 * blocks + 4, taps // 2
   rows_used = (ROWS // n) * n
-  relu = lambda x: np.maximum(x, 0.0)
+  # (relu = the [0, 1] clamp on activations scaled by 2^-RELU_SHIFT, as in emulate_tower)
+  dn, up = np.ldexp(1.0, -RELU_SHIFT), np.ldexp(1.0, RELU_SHIFT)
+  relu = lambda x: np.clip(x, 0.0, 1.0)
   bufs = [np.zeros((ROWS, hs)), np.zeros((ROWS, hs))]
   j, half = LANES & 31, LANES >> 5
-  w_in = pack_input_big(kernels[0], biases[0], taps, blocks)
+  w_in = pack_input_big(kernels[0], biases[0], taps, blocks) * dn
   steps = (taps + 2) // 2
   for wave in range(4):
     for t in range(2):
@@ -333,6 +361,7 @@ def emulate_big_tower(un_rows, n, kernels, biases, taps, blocks, groups):
   src, dst = bufs
   for l in range(1, len(kernels) - 1):
     packed, bias = pack_hidden_stream(kernels[l], biases[l], taps, blocks)
+    bias = bias * dn
     dst[:] = 0
     for wave in range(4):
       for t in range(2):
@@ -363,7 +392,7 @@ def emulate_big_tower(un_rows, n, kernels, biases, taps, blocks, groups):
       for r in range(4):
         ch = 4 * grp + r
         if ch < n_ch:
-          packed[q // 16, 4 * (q % 16) + r] = wk[k, ch] if k < kc else b[ch]
+          packed[q // 16, 4 * (q % 16) + r] = up * wk[k, ch] if k < kc else b[ch]
   out = np.zeros((ROWS, 4 * groups))
   per_tap = chans // 4
   for wave in range(4):

@@ -129,6 +129,11 @@ def test_bench_eight_ranks_on_this_box():
   for key in ('wall_ms', 'kernel_ms', 'gather_ms_isolated'):
     assert len(per_rank[key]) == 8 and all(v > 0 for v in per_rank[key]), key
   assert per_rank['gathered_shape'] == [512, 64]
+  # the 1 -> N point measured in the same invocation: rank 0 alone on its shard
+  detail = result['scaling_detail']
+  assert detail['nranks'] == 8 and detail['backend'] == 'gloo' and detail['n1_batch'] == 64
+  assert detail['n1_value'] > 0 and detail['n1_ms_per_step'] > 0
+  assert abs(detail['efficiency'] - result['value'] / (8 * detail['n1_value'])) < 1e-9
   # the single-process run of global sample ids 0 .. 511 (rank r owns [64 r, 64 r + 64))
   import bench
   args = bench.parse_args(['--batch', '512', '--steps', '5'])

@@ -1,9 +1,12 @@
 """The reference's own integration tests (integrate_test.py:47-203) re-run
 against the HIP solvers: same equations, grid sizes, time grids, tolerances
-and assertions.  The trained checkpoint is replaced by a synthetic model with
-the reference's test architecture (num_layers=1, filter_size=32 is the
-reference's `model_kwargs`; its training on noise is out of scope here), and
-the two KS cases with warmup=50 use a shorter warm-up (the explicit RK23
+and assertions -- all thirteen parameterisations of its exact / baseline /
+model triple (integrate_test.py:55-69), the three Kuramoto-Sivashinsky ones
+included.  The trained checkpoint is replaced by a synthetic model of the
+architecture those tests train: the DEFAULT three-layer net (integrate_test.py:48
+defines `model_kwargs = dict(num_layers=1, filter_size=32)` but never passes it to
+create_hparams; its training on noise is out of scope here).  The two
+single-solver KS cases with warmup=50 use a shorter warm-up (the explicit RK23
 solver needs ~3e4 evaluations per time unit on that equation)."""
 import json
 
@@ -36,6 +39,9 @@ def _assert_mean_zero(y):
     (dict(equation='kdv'), 0, True, None),
     (dict(equation='burgers', numerical_flux=True), 0, True, None),
     (dict(equation='kdv', numerical_flux=True), 0, True, None),
+    (dict(equation='ks'), 0, False, None),
+    (dict(equation='ks'), 0, True, None),
+    (dict(equation='ks', numerical_flux=True), 0, True, None),
     (dict(equation='burgers'), 1, False, None),
     (dict(equation='burgers'), 1, True, None),
     (dict(equation='kdv'), 1, True, None),

@@ -298,8 +298,8 @@ def test_other_towers_on_mfma(overrides):
     dict(num_layers=1, filter_size=8, nonlinearity='tanh'),    # (neither is used by a 1-layer net)
 ])
 def test_one_layer_nets_on_the_valu_route(overrides):
-  """num_layers = 1 -- the model of the reference's own integration tests
-  (integrate_test.py:48: model_kwargs = dict(num_layers=1, filter_size=32)) -- has no
+  """num_layers = 1 (training.create_hparams admits it; integrate_test.py:48 names it in
+  `model_kwargs` but never passes it, so the reference's own tests train three layers) has no
   hidden activations: its coefficients are affine in the K neighbouring values, folded on
   the host (conv layer x null space + accuracy bias) and evaluated on the VALU route of the
   MFMA-path kernels (DevParams::linear_taps) instead of the generic kernel.  Every equation
