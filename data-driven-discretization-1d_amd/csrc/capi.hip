@@ -42,6 +42,7 @@ struct DebugOptions {
   int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
   int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
   int no_lean = 0;       // the MFMA-path kernels (tower skipped) instead of rhs_lean.h
+  int no_fft = 0;        // spectral models: the O(N^2) circulant form at every N
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
   int substep_parts = 0; // A/B: sample slabs advanced side by side in the per-substep modes (0: auto)
@@ -210,6 +211,8 @@ struct ddd_model {
   bool spectral = false;
   ddd::spectral::Params sp{};
   double* d_kernels = nullptr;
+  double2* d_fft_mult = nullptr;      // FFT mode (rhs_spectral.h): multipliers [D][N] and
+  double2* d_fft_twiddle = nullptr;   // the twiddle table [N / 2]
   double* d_scratch64 = nullptr;
   size_t scratch64_doubles = 0;
   // per-substep launch mode: the ensemble is advanced as two half-ensembles on two
@@ -1451,6 +1454,40 @@ int ddd_spectral_create(const ddd_config* cfg, const double* kernels, size_t n_k
     return fail(DDD_ERR_HIP, "spectral kernels upload: %s", hipGetErrorString(e));
   }
   m->sp.kernels = m->d_kernels;
+  // FFT mode for the large exact grids (N a power of two >= 512; rhs_spectral.h): the same
+  // D circulant operators as diagonal multipliers in Fourier space, mult[d] = DFT(kernel[d]).
+  // Formed HERE from the caller's kernels, so every Nyquist / sign convention of the call
+  // that produced them carries over unchanged; a direct O(N^2) DFT in long double (once per
+  // model: 12 M complex terms at N = 2048, D = 3), twiddles exp(-2 pi i m / N) likewise.
+  const int n = cfg->num_points;
+  if (n >= ddd::spectral::kFftMinPoints && (n & (n - 1)) == 0 && !g_debug.no_fft) {
+    const long double two_pi = 6.283185307179586476925286766559005768L;
+    std::vector<long double> cs(n), sn(n);
+    for (int j = 0; j < n; ++j) {
+      cs[j] = cosl(two_pi * (long double)j / (long double)n);
+      sn[j] = sinl(two_pi * (long double)j / (long double)n);
+    }
+    std::vector<double2> mult((size_t)cfg->num_derivatives * n), tw(n / 2);
+    for (int d = 0; d < cfg->num_derivatives; ++d)
+      for (int k = 0; k < n; ++k) {
+        long double re = 0.0L, im = 0.0L;
+        for (int j = 0; j < n; ++j) {
+          const int a = (int)(((long long)j * k) % n);
+          const long double c = (long double)kernels[(size_t)d * n + j];
+          re += c * cs[a];
+          im -= c * sn[a];
+        }
+        mult[(size_t)d * n + k] = make_double2((double)re, (double)im);
+      }
+    for (int i = 0; i < n / 2; ++i) tw[i] = make_double2((double)cs[i], (double)-sn[i]);
+    int rc2 = upload(mult, &m->d_fft_mult);
+    if (rc2 == DDD_OK) rc2 = upload(tw, &m->d_fft_twiddle);
+    if (rc2 != DDD_OK) { ddd_model_destroy(m); return rc2; }
+    m->sp.fft_mult = m->d_fft_mult;
+    m->sp.fft_twiddle = m->d_fft_twiddle;
+    m->sp.fft_log2n = 31 - __builtin_clz((unsigned)n);
+    m->fma_per_point = (int64_t)(2 + (cfg->num_derivatives + 1) / 2) * 5 * m->sp.fft_log2n / 2;
+  }
   *out = m;
   return DDD_OK;
 }
@@ -1518,6 +1555,8 @@ int ddd_model_destroy(ddd_model* m) {
   }
   if (m->ev_fork != nullptr) (void)hipEventDestroy(m->ev_fork);
   if (m->d_kernels != nullptr) (void)hipFree(m->d_kernels);
+  if (m->d_fft_mult != nullptr) (void)hipFree(m->d_fft_mult);
+  if (m->d_fft_twiddle != nullptr) (void)hipFree(m->d_fft_twiddle);
   if (m->d_scratch64 != nullptr) (void)hipFree(m->d_scratch64);
   delete m;
   return DDD_OK;
@@ -1965,8 +2004,13 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   std::memcpy(slot.host, times, (size_t)n_times * sizeof(double));
   DDD_HIP(hipMemcpyAsync(slot.dev, slot.host, (size_t)n_times * sizeof(double),
                          hipMemcpyHostToDevice, stream));
+  // the slot is busy from HERE on (the copy reads the pinned buffer), whatever happens to
+  // the launch below: an error return between the copy and the launch must not leave a
+  // slot that looks free while the copy is still pending
+  DDD_HIP(hipEventRecord(slot.done, stream));
+  slot.in_flight = true;
   ddd::AdaptiveArgs a{};
-  // the slot is free again once the launch enqueued below has run
+  // ... and is free again once the launch enqueued below has run
   const auto enqueued = [&]() -> int {
     DDD_HIP(hipGetLastError());
     DDD_HIP(hipEventRecord(slot.done, stream));
@@ -2229,6 +2273,7 @@ DDD_API int ddd_debug_set_option(const char* name, long long value) {
   else if (key == "no_spec") g_debug.no_spec = (int)value;
   else if (key == "no_stream") g_debug.no_stream = (int)value;
   else if (key == "no_lean") g_debug.no_lean = (int)value;
+  else if (key == "no_fft") g_debug.no_fft = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;
   else if (key == "substep_parts") g_debug.substep_parts = (int)value;

@@ -39,8 +39,22 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
                                              double* red) {
   if (kRows == kWR) {
     // one wavefront, N | 64 (a power of two): xor butterfly inside aligned
-    // groups of N lanes; a + b == b + a, so every lane ends with the same bits
+    // groups of N lanes; a + b == b + a, so every lane ends with the same bits.
+    // ds_bpermute at (lane ^ m) * 4 directly: __shfl_xor spends nine VALU instructions per
+    // step on its width check and index math (54 per error norm, on lanes the MFMA pipe
+    // shares); here one v_xor per step -- lane ^ m never leaves an aligned group of N > m.
+#if !DDD_ADAPTIVE_BUTTERFLY
     for (int m = 1; m < p.N; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+#endif
+    const int lane4 = ln.lane << 2;
+    for (int m = 1; m < p.N; m <<= 1) {
+      const int src = lane4 ^ (m << 2);
+      const long long bits = __double_as_longlong(v);
+      const int lo = __builtin_amdgcn_ds_bpermute(src, (int)bits);
+      const int hi = __builtin_amdgcn_ds_bpermute(src, (int)(bits >> 32));
+      v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
     return v;
   }
   // four-wave groups: `red` aliases Shared::un + Shared::flux (free between two
@@ -104,8 +118,27 @@ static_assert(sizeof(Shared<64>) + sizeof(AdaptiveShared<64>) <= 20 * 1024, "8 g
 #ifndef DDD_ADAPTIVE_LEAN
 #define DDD_ADAPTIVE_LEAN 0   // A/B (profiles/r4_ablation.txt): bit 0 = 64-row groups lean, bit 1 = 256-row
 #endif
+// eval_rhs's kLean for the adaptive kernels: 1 = output-layer weights and cos / sin table
+// fetched per evaluation (the A/B above), 2 = the table only (two ds_read_b128 from the
+// LDS row padding instead of 12 resident registers: the controller's live values -- state
+// and three stage derivatives in float64 / float32, the next output time -- need them)
+#ifndef DDD_ADAPTIVE_TRIG_LDS
+#define DDD_ADAPTIVE_TRIG_LDS 0   // measured (gpurun_out/r5d): resident 77.7 / 72.1 / 66.4 %, LDS / L2 77.2 / 71.8 / 66.3 %
+#endif
+// A/B switches of round 5's controller slimming (profiles/r5_ablation.txt)
+#ifndef DDD_ADAPTIVE_SHORTCUT
+#define DDD_ADAPTIVE_SHORTCUT 1   // stages 2 / 3 without controller load / store / vote
+#endif
+#ifndef DDD_ADAPTIVE_PREFETCH
+#define DDD_ADAPTIVE_PREFETCH 1   // next output time requested during stage 3
+#endif
+#ifndef DDD_ADAPTIVE_BUTTERFLY
+#define DDD_ADAPTIVE_BUTTERFLY 1  // ds_bpermute at lane ^ m directly instead of __shfl_xor
+#endif
 template <int kRows>
-constexpr bool adaptive_lean() { return ((kRows == 64 ? 1 : 2) & DDD_ADAPTIVE_LEAN) != 0; }
+constexpr int adaptive_lean() {
+  return ((kRows == 64 ? 1 : 2) & DDD_ADAPTIVE_LEAN) != 0 ? 1 : (DDD_ADAPTIVE_TRIG_LDS ? 2 : 0);
+}
 
 template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false, class TW = DefaultTower>
 __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) void adaptive_kernel(
@@ -143,7 +176,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   };
   // forcing sums computed outside an evaluation (the first stage of every attempt): the
   // masked first trip of forcing_phase2 where the evaluation keeps the masks resident anyway
-  constexpr bool kMaskedSums = kHoist && kWR == 64 && kEq >= 0 && !adaptive_lean<kRows>() &&
+  constexpr bool kMaskedSums = kHoist && kWR == 64 && kEq >= 0 && adaptive_lean<kRows>() != 1 &&
                                spec_folded(kEq >= 0 ? kEq : 0);
 
   // The step-size controllers live in LDS, one per sample of the group: their 7
@@ -168,6 +201,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   double y = ln.valid ? a.y0[ln.gidx] : 0.0;
   double y_new = y;
   float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f;
+  double te_next = 0.0;   // times[ti] of the lane's sample, requested one evaluation ahead
 
   // phase 0: f(t0, y0); 1: the probe of select_initial_step; 2..4: stages 2, 3
   // and the FSAL stage of one attempt.  Uniform over the workgroup.
@@ -218,6 +252,28 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>(), TW>(
         p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
     sums_ready = ahead;
+    if (DDD_ADAPTIVE_SHORTCUT && (phase == 2 || phase == 3)) {
+      // Stages 2 and 3 of an attempt change nothing of the controller but the evaluation
+      // count, and no sample can finish here: no controller load / unpack / store, no vote
+      // (two of every three evaluations).  Stage 3 also requests the next output time: the
+      // dense-output loop after stage 4 used to wait a global-memory round trip for it in
+      // every attempt.
+      const bool run = ctl[slot].status() == rk23::RUNNING;
+      if (phase == 2) {
+        k1 = f;
+        phase = 3;
+      } else {
+        k2 = f;
+        y_new = rk23::new_state(y, k0, k1, k2, ctl[slot].h);
+        if (DDD_ADAPTIVE_PREFETCH) {
+          const int ti = ctl[slot].bits >> 3;
+          te_next = a.times[ti < a.n_times ? ti : a.n_times - 1];
+        }
+        phase = 4;
+      }
+      if (keeper && run) ctl[slot].nfev += 1;   // (the keeper alone touches this field)
+      continue;
+    }
     // (eval_rhs's barriers are compiler barriers too: this is a fresh read)
     rk23::Control c = ctl[slot].load();
     if (c.status == rk23::RUNNING) ++c.nfev;
@@ -246,27 +302,29 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
       c.begin_step(max_step);
       c.begin_attempt(t_bound);
       phase = 2;
-    } else if (phase == 2) {
+    } else if (!DDD_ADAPTIVE_SHORTCUT && phase == 2) {
       k1 = f;
       phase = 3;
-    } else if (phase == 3) {
+    } else if (!DDD_ADAPTIVE_SHORTCUT && phase == 3) {
       k2 = f;
       y_new = rk23::new_state(y, k0, k1, k2, c.h);
       phase = 4;
-    } else {
+    } else {   // phase 4 (2 and 3: above)
       const float k3 = f;
       const double error_norm =
           rms(rk23::scaled_error(y, y_new, k0, k1, k2, k3, c.h, rtol, atol));
       if (c.status == rk23::RUNNING && c.error_test(error_norm)) {
         // solve_ivp: dense output at every t_eval in (t_old, t_new]
+        // (times[c.ti] was requested during stage 3: te_next)
+        double te = DDD_ADAPTIVE_PREFETCH ? te_next : a.times[c.ti < a.n_times ? c.ti : a.n_times - 1];
         while (c.ti < a.n_times) {
-          const double te = a.times[c.ti];
           if (!(te <= c.t_new)) break;
           // (spare rows of a 256-row group follow sample 0's controller: no stores)
           if (ln.active)
             a.y_out[(size_t)c.ti * row_stride + ln.gidx] =
                 rk23::dense_output(y, k0, k1, k2, k3, (te - c.t) / c.h, c.h);
           ++c.ti;
+          if (c.ti < a.n_times) te = a.times[c.ti];
         }
         y = y_new;
         k0 = k3;

@@ -50,7 +50,7 @@ static_assert(sizeof(Shared) <= 8 * 1024, "LDS per wavefront: 20 wavefronts per 
 inline bool supports(const DevParams& p) {
   if (!(p.fixed || p.linear_taps > 0) || p.weno) return false;
   if (p.N < 8 || p.N > 64 || 64 % p.N != 0) return false;
-  if (p.G < 3 || p.G > kGMax || p.D < 1 || p.D > kMaxDerivs) return false;
+  if (p.G < 1 || p.G > kGMax || p.G > p.N || p.D < 1 || p.D > kMaxDerivs) return false;
   if (p.linear_taps > 0 && (p.linear_taps > 7 || p.D > 3 || p.target != TARGET_COEFFICIENTS))
     return false;
   if (p.fixed && p.target != TARGET_COEFFICIENTS) return false;

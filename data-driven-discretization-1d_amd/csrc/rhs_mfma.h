@@ -1000,7 +1000,9 @@ __device__ __forceinline__ float forcing_sums(const DevParams& p, Shared<kRows, 
 // kLean (adaptive integrators): the output layer's weights and the cos / sin table
 // are NOT kept resident (fetched from L2 / the LDS row padding per evaluation like
 // the run-time kernels do): 31-43 VGPRs the controller state needs.
-template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide, bool kLean = false,
+// (kLean = 2: only the cos / sin table leaves the registers -- 12 VGPRs for two ds_read_b128
+// per evaluation; the round-5 adaptive kernels)
+template <int kRows, int kWR, bool kHoist, int kEq, bool kTrace, bool kWide, int kLean = 0,
           class TW = DefaultTower>
 __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm, int batch,
                                           float u, float t, float t_next, Resident& res,
@@ -1057,7 +1059,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // bits equal the one-wavefront kernel's.
   constexpr bool kSplit = kSpec && kRows == 64 && kWR == 32 && kHoist;
   constexpr bool kKeepOffsets = (kWR == 64 || kSplit) && kHoist;
-  constexpr bool kKeepRows = kKeepOffsets && kEq >= 0 && !kLean;
+  constexpr bool kKeepRows = kKeepOffsets && kEq >= 0 && kLean != 1;
   constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
   const int tid = opaque(group_tid<kRows, kWR>());
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
@@ -1337,7 +1339,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // the epilogue, consumed by its last statement
   float4 trig4[kTrigMax / 4];
   if (forced && fast_forcing) {
-    if (kKeepOffsets && !kLean) {
+    if (kKeepOffsets && kLean == 0) {
       // resident for the launch: lane == grid point never changes
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) trig4[i] = res.trig[i];
@@ -1549,7 +1551,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       float total = 0.0f;
 #pragma unroll
       for (int i = 0; i < kTrigMax / 4; ++i) {
-        if (i == 2 && trig_lds && !(kKeepOffsets && !kLean)) break;   // entries 8..11 are zero padding
+        if (i == 2 && trig_lds && !(kKeepOffsets && kLean == 0)) break;   // entries 8..11 are zero padding
         const float4 f = fk4[i];
         total = fmaf(f.x, trig4[i].x, total);
         total = fmaf(f.y, trig4[i].y, total);

@@ -30,7 +30,15 @@ struct Params {
   int equation, N, D;
   double eta;
   const double* kernels;   // [D][N] circulant first columns
+  // FFT mode (N a power of two >= kFftMinPoints; round 5): the same D operators as
+  // diagonal multipliers in Fourier space, mult[d][k] = DFT(kernels[d])[k] (formed on the
+  // host in extended precision, capi.hip: ddd_spectral_create), and the twiddle table
+  // exp(-2 pi i m / N), m < N / 2.  fft_log2n = 0: circulant mode.
+  const double2* fft_mult;
+  const double2* fft_twiddle;
+  int fft_log2n;
 };
+constexpr int kFftMinPoints = 512;   // below: the O(N^2) circulant form wins (profiles/r3_spectral_exact.txt)
 
 struct SubstepArgs64 {
   const double* y_in;
@@ -43,7 +51,10 @@ struct SubstepArgs64 {
   int batch;
 };
 
+// circulant mode: the stage input + the D kernels; FFT mode: the stage input, three
+// complex work buffers (spectrum, product, ping-pong partner) and the twiddle table
 __host__ __device__ inline size_t lds_bytes(const Params& p) {
+  if (p.fft_log2n > 0) return (size_t)8 * p.N * sizeof(double);
   return (size_t)(1 + p.D) * p.N * sizeof(double);
 }
 
@@ -58,6 +69,111 @@ __device__ __forceinline__ double equation_rhs(int eq, double y, const double (&
   }
 }
 
+// ---------------------------------------------------------------------------
+// FFT mode (round 5): for N >= 512 the O(N^2) circulant products lose to an FFT
+// (156 us per right-hand side at N = 512 and 4.3 ms at N = 2048 against 90 / 170 us
+// for a rocFFT rfft -> multiply -> irfft chain of several launches,
+// profiles/r3_spectral_exact.txt).  One workgroup per sample as before; the sample's
+// spectrum never leaves LDS:
+//   Y = FFT(u);  Z = Y m_0 + i Y m_1;  IFFT(Z) = deriv_0 + i deriv_1
+// (two real derivatives per complex inverse: Y is Hermitian and the multipliers are
+// the DFTs of REAL circulant kernels), a second inverse for a third derivative (KS).
+// Radix-2 Stockham autosort (natural order in and out, no bit reversal), float64,
+// N / 2 butterflies per stage over 256 threads, twiddles from an LDS table.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+  return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// All threads of the workgroup.  x: input (complete, synchronised), y: partner buffer.
+// Returns the buffer holding the transform (x or y).  kInverse: conjugate twiddles, no
+// 1 / N (the caller scales).
+template <bool kInverse>
+__device__ __forceinline__ double2* fft_pow2(double2* x, double2* y, const double2* __restrict__ tw,
+                                             int n, int log2n) {
+  const int half = n >> 1;
+  for (int s = 0; s < log2n; ++s) {
+    const int ns = 1 << s;                    // half-size of the sub-transforms being merged
+    const int tstride = half >> s;            // twiddle exp(-2 pi i k / (2 ns)) = tw[k * tstride]
+    for (int j = (int)threadIdx.x; j < half; j += kThreads) {
+      const int k = j & (ns - 1);
+      double2 w = tw[k * tstride];
+      if (kInverse) w.y = -w.y;
+      const double2 a = x[j];
+      const double2 b = cmul(w, x[j + half]);
+      const int j0 = ((j - k) << 1) + k;
+      y[j0] = make_double2(a.x + b.x, a.y + b.y);
+      y[j0 + ns] = make_double2(a.x - b.x, a.y - b.y);
+    }
+    __syncthreads();
+    double2* t = x; x = y; y = t;
+  }
+  return x;
+}
+
+// The D derivatives of the sample whose stage input sits in u[0 .. N) (complete,
+// synchronised), at the points this thread owns (pos = tid + i kThreads), and the
+// equation of motion.  work: 3 N double2 + N / 2 double2 of twiddles (lds_bytes).
+template <int kPts>
+__device__ __forceinline__ void eval_points_fft(const Params& p, const double* __restrict__ u,
+                                                double2* work, double (&f)[kPts]) {
+  const int n = p.N, tid = (int)threadIdx.x;
+  double2* spec = work;            // the spectrum Y (kept across both inverses)
+  double2* b0 = work + n;
+  double2* b1 = work + 2 * n;
+  const double2* tw = work + 3 * n;
+  for (int i = tid; i < n; i += kThreads) b0[i] = make_double2(u[i], 0.0);
+  __syncthreads();
+  {
+    double2* y = fft_pow2<false>(b0, b1, tw, n, p.fft_log2n);
+    for (int i = tid; i < n; i += kThreads) spec[i] = y[i];
+    __syncthreads();
+  }
+  const double inv_n = 1.0 / (double)n;
+  double dv[kPts][kMaxDerivs];
+#pragma unroll
+  for (int i = 0; i < kPts; ++i)
+#pragma unroll
+    for (int d = 0; d < kMaxDerivs; ++d) dv[i][d] = 0.0;
+  for (int d0 = 0; d0 < p.D; d0 += 2) {       // derivatives (d0, d0 + 1) per inverse transform
+    const bool pair = d0 + 1 < p.D;
+    for (int k = tid; k < n; k += kThreads) {
+      const double2 yk = spec[k];
+      double2 z = cmul(yk, p.fft_mult[(size_t)d0 * n + k]);
+      if (pair) {
+        const double2 z1 = cmul(yk, p.fft_mult[(size_t)(d0 + 1) * n + k]);
+        z.x -= z1.y;                           // z + i z1
+        z.y += z1.x;
+      }
+      b0[k] = z;
+    }
+    __syncthreads();
+    const double2* r = fft_pow2<true>(b0, b1, tw, n, p.fft_log2n);
+#pragma unroll
+    for (int i = 0; i < kPts; ++i) {
+      const int pos = tid + i * kThreads;
+      if (pos >= n) continue;
+      const double2 v = r[pos];
+#pragma unroll
+      for (int d = 0; d < kMaxDerivs; ++d) {   // (compile-time register indices)
+        if (d == d0) dv[i][d] = v.x * inv_n;
+        if (pair && d == d0 + 1) dv[i][d] = v.y * inv_n;
+      }
+    }
+    __syncthreads();                           // r is rewritten by the next product
+  }
+#pragma unroll
+  for (int i = 0; i < kPts; ++i) {
+    const int pos = tid + i * kThreads;
+    f[i] = pos < n ? equation_rhs(p.equation, u[pos], dv[i], p.eta) : 0.0;
+  }
+}
+
+__device__ __forceinline__ void load_twiddles(const Params& p, double2* work) {
+  double2* tw = work + 3 * p.N;
+  for (int i = (int)threadIdx.x; i < p.N / 2; i += kThreads) tw[i] = p.fft_twiddle[i];
+}
+
 __global__ __launch_bounds__(kThreads) void substep_kernel(Params p, SubstepArgs64 a) {
   extern __shared__ __attribute__((aligned(16))) double smem64[];
   double* y = smem64;
@@ -65,19 +181,28 @@ __global__ __launch_bounds__(kThreads) void substep_kernel(Params p, SubstepArgs
   const int n = p.N;
   const size_t off = (size_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += kThreads) y[i] = a.y_in[off + i];
-  for (int i = threadIdx.x; i < p.D * n; i += kThreads) c[i] = p.kernels[i];
+  if (p.fft_log2n > 0) load_twiddles(p, reinterpret_cast<double2*>(c));
+  else for (int i = threadIdx.x; i < p.D * n; i += kThreads) c[i] = p.kernels[i];
   __syncthreads();
-  for (int pos = threadIdx.x; pos < n; pos += kThreads) {
+  double fft_f[kMaxPoints / kThreads];
+  if (p.fft_log2n > 0)   // (uniform over the workgroup)
+    eval_points_fft<kMaxPoints / kThreads>(p, y, reinterpret_cast<double2*>(c), fft_f);
+  for (int pos = threadIdx.x, it = 0; pos < n; pos += kThreads, ++it) {
     double dv[kMaxDerivs] = {0.0, 0.0, 0.0, 0.0};
     int idx = pos;   // (pos - j) mod N
-    for (int j = 0; j < n; ++j) {
+    for (int j = 0; j < n && p.fft_log2n == 0; ++j) {
       const double yj = y[j];
 #pragma unroll
       for (int d = 0; d < kMaxDerivs; ++d)
         if (d < p.D) dv[d] = fma(c[d * n + idx], yj, dv[d]);
       idx = idx == 0 ? n - 1 : idx - 1;
     }
-    const double f = equation_rhs(p.equation, y[pos], dv, p.eta);
+    double f = equation_rhs(p.equation, y[pos], dv, p.eta);
+    if (p.fft_log2n > 0) {
+      // (compile-time register index: the thread's `it`-th point)
+#pragma unroll
+      for (int q = 0; q < kMaxPoints / kThreads; ++q) if (q == it) f = fft_f[q];
+    }
     const size_t gi = off + pos;
     if (a.y_out != nullptr) {
       const double cf = a.c1 * f;
@@ -129,7 +254,9 @@ __global__ __launch_bounds__(kThreads) void adaptive_kernel(Params p, AdaptiveAr
   const int tid = (int)threadIdx.x;
   const size_t off = (size_t)blockIdx.x * n;
   const size_t row_stride = (size_t)a.batch * n;
-  for (int i = tid; i < p.D * n; i += kThreads) c[i] = p.kernels[i];
+  const bool use_fft = p.fft_log2n > 0;   // (uniform)
+  if (use_fft) load_twiddles(p, reinterpret_cast<double2*>(c));
+  else for (int i = tid; i < p.D * n; i += kThreads) c[i] = p.kernels[i];
 
   const double t0 = a.times[0];
   const double t_bound = a.times[a.n_times - 1];
@@ -170,7 +297,8 @@ __global__ __launch_bounds__(kThreads) void adaptive_kernel(Params p, AdaptiveAr
       u[pos] = yy;
     }
     __syncthreads();
-    eval_points<kPts>(p, u, c, f);
+    if (use_fft) eval_points_fft<kPts>(p, u, reinterpret_cast<double2*>(c), f);
+    else eval_points<kPts>(p, u, c, f);
     __syncthreads();
     ++ctl.nfev;
     double q[kPts];

@@ -1,9 +1,10 @@
 """Exact (spectral, float64) solver on the device: throughput of the batched
 adaptive RK23 solve and the cost of ONE right-hand-side evaluation of the
-O(N^2) circulant kernel against an FFT evaluation through rocFFT
+spectral kernel (O(N^2) circulant products below 512 points, the in-LDS FFT of
+round 5 from 512 up) against an FFT evaluation through rocFFT
 (torch.fft.rfft / irfft on the same device, same batch), N = 64 ... 2048.
 
-  python profiles/tools/spectral_exact_bench.py > profiles/r3_spectral_exact.txt
+  python profiles/tools/spectral_exact_bench.py > profiles/r5_spectral_exact.txt
 """
 import os
 import sys
@@ -41,8 +42,8 @@ def fft_rhs(cls, y, period, eta=0.04):
   return eta * d(2) - y * d(1)
 
 
-print('# one right-hand-side evaluation, float64, batch 1024: circulant kernel vs rocFFT')
-print('# equation N  circulant_us  rocfft_us  ratio(circulant/rocfft)  max_abs_diff')
+print('# one right-hand-side evaluation, float64, batch 1024: spectral kernel (mode) vs rocFFT')
+print('# equation N mode  ours_us  rocfft_us  ratio(ours/rocfft)  max_rel_diff')
 for cls in (equations.KdVEquation, equations.KSEquation):
   for n in (64, 128, 256, 512, 1024, 2048):
     eq = cls(n, random_seed=0)
@@ -52,8 +53,9 @@ for cls in (equations.KdVEquation, equations.KSEquation):
     fft = timed(lambda: fft_rhs(cls, y, eq.grid.period), 20) * 1e3
     diff = (model.time_derivative(y) - fft_rhs(cls, y, eq.grid.period)).abs().max().item()
     scale = model.time_derivative(y).abs().max().item()
-    print('{} {:5d} {:10.1f} {:10.1f} {:6.2f} {:.1e}'.format(
-        cls.__name__, n, ours, fft, ours / fft, diff / scale))
+    mode = 'fft' if n >= 512 and n & (n - 1) == 0 else 'circulant'
+    print('{} {:5d} {:9s} {:10.1f} {:10.1f} {:6.2f} {:.1e}'.format(
+        cls.__name__, n, mode, ours, fft, ours / fft, diff / scale))
 
 print('# integrate_exact_batch: SciPy-RK23 semantics per sample, one launch per segment')
 print('# config samples nfev_min nfev_max wall_s grid_point_evals_per_s')

@@ -135,6 +135,62 @@ def test_spectral_batched_and_rfft_convention():
     model_lib.SpectralModel.time_derivative(base, random_phase_ic(base.equation, 2).astype(np.float64))
 
 
+@pytest.mark.parametrize('cls_name,n,batch', [('KdVEquation', 512, 9), ('KSEquation', 512, 5),
+                                              ('KSEquation', 1024, 3), ('KdVEquation', 2048, 2),
+                                              ('BurgersEquation', 512, 4)])
+def test_spectral_fft_mode_vs_reference_operator(cls_name, n, batch):
+  """N >= 512: the spectral right-hand side runs as an in-LDS float64 FFT
+  (rhs_spectral.h: eval_points_fft; multipliers = DFT of the very circulant kernels the
+  smaller grids apply directly) -- against scipy.fftpack.diff / numpy.fft on the host,
+  both conventions.  Bound: float64 rounding x the largest multiplier of the equation's
+  highest derivative (the reference's own FFT has that noise too), far below 1e-9."""
+  eq = getattr(equations, cls_name)(n, random_seed=3)
+  y = random_phase_ic(eq, batch).astype(np.float64)
+  spec = eq.kernel_spec()
+  kmax = 2 * np.pi * (n // 2) / spec['period']
+  bound = max(TOL64, 200 * np.finfo(np.float64).eps * kmax ** max(spec['derivative_orders']))
+  for convention in ('fftpack', 'rfft'):
+    model = model_lib.SpectralModel(eq, convention=convention)
+    got = model.time_derivative(y).cpu().numpy()
+    if convention == 'fftpack':
+      want = oracle.spectral_time_derivative(spec['equation'], y, spec['derivative_orders'],
+                                             spec['period'], spec['eta'], spec['dx'])
+    else:
+      derivs = np.stack([oracle.spectral_derivative(y, order, spec['period'])
+                         for order in spec['derivative_orders']], axis=-1)
+      want = oracle.equation_of_motion(spec['equation'], y, derivs, spec['eta'], spec['dx'])
+    err = rel_err(got, want)
+    print(cls_name, n, convention, 'fft-mode rhs rel err {:.2e} (bound {:.1e})'.format(err, bound))
+    assert err < bound
+
+
+def test_spectral_fft_mode_adaptive_exact_solver():
+  """integrate_exact on a 512-point KdV grid (the exact grid of integrate_test-style runs
+  at resample factor 8): the batched device solver in FFT mode against SciPy's RK23 over
+  the host restatement of SpectralDifferentiator -- equal evaluation counts, 1e-9.  With a
+  SATURATED controller (max_step below the stability limit of u_xxx on dx = 1/16): at the
+  reference's max_step this grid sits on the stability boundary, where accept / reject
+  decisions amplify rounding noise (2 552 vs 2 576 evaluations between two float64
+  evaluations of the same operator, gpurun_out/r5d) -- as for KS N = 256."""
+  import scipy.integrate
+  eq = equations.KdVEquation(512, random_seed=2)
+  model = model_lib.SpectralModel(eq)
+  spec = eq.kernel_spec()
+  y0 = np.stack([eq.initial_value(), equations.KdVEquation(512, random_seed=5).initial_value()])
+  times = np.linspace(0.0, 5e-4, 3)
+  max_step = 5e-6    # (k_max^3 = 1.3e5: the explicit RK23 stability limit is ~1.3e-5)
+  y, nfev, status = model.integrate_adaptive(y0, times, max_step=max_step)
+  y = y.cpu().numpy()
+  assert (status.cpu().numpy() == 0).all()
+  rhs = lambda t, v: oracle.spectral_time_derivative(
+      spec['equation'], v, spec['derivative_orders'], spec['period'], spec['eta'], spec['dx'])
+  for b in range(2):
+    sol = scipy.integrate.solve_ivp(rhs, (times[0], times[-1]), y0[b], t_eval=times,
+                                    max_step=max_step, method='RK23')
+    assert sol.nfev == int(nfev[b]), (b, sol.nfev, int(nfev[b]))
+    assert rel_err(y[:, b], sol.y.T) < 1e-9
+
+
 def test_spectral_fixed_step_f64_vs_oracle():
   """ddd_integrate_fixed_f64 on a spectral model: BS3 in float64 end to end."""
   eq = equations.KdVEquation(64, random_seed=1)

@@ -11,7 +11,7 @@ is asserted, the measured value is printed.
 import numpy as np
 import pytest
 
-from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err)
+from helpers import (oracle, make_model, random_phase_ic, batch_forcing, rel_err, FLOOR_CEILING)
 
 pytestmark = pytest.mark.gpu
 
@@ -91,6 +91,7 @@ def _measured_tol(spec, y0, t, forcing, want):
                                        spec['resample_factor'], spec['period'],
                                        spec['conservative'])
   floor = rel_err(want, truth)
+  assert floor < FLOOR_CEILING, ('float32 oracle vs float64 evaluation', floor)   # (never relax silently)
   return max(TOL, 4 * floor), floor
 
 
