@@ -244,22 +244,28 @@ __device__ __forceinline__ double pick4(int s, double v0, double v1, double v2, 
       : "=&s"(r) : "s"(s), "s"(v0), "s"(v1), "s"(v2), "s"(v3) : "scc");
   return r;
 }
-template <typename T>
+// kSgpr = false: a plain indexed read (one scalar load per use) -- the run-time-parameterised
+// kernels have no 16 SGPRs to spare for the whole time loop (their model scalars already
+// spill: with the selects they went from 42 to 74 SGPR spills, each a v_readlane per use).
+template <typename T, bool kSgpr = true>
 struct StagePick {
   const T (&v)[kMaxStages];
   __device__ __forceinline__ explicit StagePick(const T (&v_)[kMaxStages]) : v(v_) {}
-  __device__ __forceinline__ T at(int s) const { return pick4(s, v[0], v[1], v[2], v[3]); }
+  __device__ __forceinline__ T at(int s) const {
+    if constexpr (kSgpr) return pick4(s, v[0], v[1], v[2], v[3]);
+    else return v[s];
+  }
 };
 // a[s] h and b[s] h in the state's type
-template <typename ST>
-__device__ __forceinline__ StagePick<ST> stage_ah(const StageConsts& sc) {
-  if constexpr (sizeof(ST) == 4) return StagePick<ST>(sc.ah);
-  else return StagePick<ST>(sc.ahd);
+template <typename ST, bool kSgpr>
+__device__ __forceinline__ StagePick<ST, kSgpr> stage_ah(const StageConsts& sc) {
+  if constexpr (sizeof(ST) == 4) return StagePick<ST, kSgpr>(sc.ah);
+  else return StagePick<ST, kSgpr>(sc.ahd);
 }
-template <typename ST>
-__device__ __forceinline__ StagePick<ST> stage_bh(const StageConsts& sc) {
-  if constexpr (sizeof(ST) == 4) return StagePick<ST>(sc.bh);
-  else return StagePick<ST>(sc.bhd);
+template <typename ST, bool kSgpr>
+__device__ __forceinline__ StagePick<ST, kSgpr> stage_bh(const StageConsts& sc) {
+  if constexpr (sizeof(ST) == 4) return StagePick<ST, kSgpr>(sc.bh);
+  else return StagePick<ST, kSgpr>(sc.bhd);
 }
 
 struct Lane {
@@ -393,6 +399,12 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 
 #define DDD_MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.885390081777927f);   // exp(-2 |x|)
+  const float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+  return copysignf(q, x);
+}
+
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
   if (act == ACT_RELU) {
 #if DDD_RELU_CLAMP
@@ -425,8 +437,13 @@ __device__ __forceinline__ void activate16(f32x16& acc, int act) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
   } else if (act == ACT_TANH) {
+    // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|): one v_exp_f32 and one v_rcp_f32
+    // (seven instructions) instead of the library's ~30 per element -- 192 elements per lane
+    // and evaluation in a four-layer net.  Absolute error <= 2e-7 (argument rounding 1.7e-7 x
+    // t <= 0.37, one ulp each of exp2 and rcp on values <= 1, two roundings), measured
+    // against float64 tanh in tests/test_cpu_mfma_emulation.py; NaN propagates, +-Inf -> +-1.
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = tanhf(acc[r]);
+    for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
   } else if (act == ACT_SOFTPLUS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = apply_activation(acc[r], ACT_SOFTPLUS);
@@ -1662,7 +1679,12 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   // cos / sin of this grid point's spatial phases (requested LAST: the register
   // allocator copies one of these values right after the load, and that wait
   // must not sit in front of the other requests)
-  float4 trg[kTrigMax / 4];   // (read under `fast` only)
+  // (defined on both paths: declared without a value and loaded under `fast`, the array
+  // lived in a 64-byte SCRATCH frame -- a store and a load per thread and launch, which
+  // the one-launch-per-substep kernels paid in HBM writes, profiles/r5_spill_table.txt)
+  float4 trg[kTrigMax / 4];
+#pragma unroll
+  for (int i = 0; i < kTrigMax / 4; ++i) trg[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (fast) {   // wave-uniform
     const float4* __restrict__ tr =
         reinterpret_cast<const float4*>(p.trig) + (size_t)ln.pos * (kTrigMax / 4);
@@ -2044,8 +2066,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   // (the per-stage products a[s] h, b[s] h, c[s] dt: StageConsts, formed on the host in this
   // arithmetic -- (ST)a[s] * (ST)dt etc. -- and picked by scalar selects)
   (void)h;
-  const StagePick<ST> ah = stage_ah<ST>(a.sc), bh = stage_bh<ST>(a.sc);
-  const StagePick<double> ct(a.sc.ct);
+  constexpr bool kSgprStages = kEq >= 0;   // (per-equation kernels: SGPRs to spare)
+  const StagePick<ST, kSgprStages> ah = stage_ah<ST, kSgprStages>(a.sc), bh = stage_bh<ST, kSgprStages>(a.sc);
+  const StagePick<double, kSgprStages> ct(a.sc.ct);
   for (int step = 0; step < a.n_steps; ++step) {
     const double t = a.t0 + (double)step * a.dt;
     const double t_after = a.t0 + (double)(step + 1) * a.dt;

@@ -12,6 +12,7 @@
 // cases keep the per-sample kernels (rhs_mfma.h / rhs_generic.h).
 #pragma once
 #include "dev_params.h"
+#include "rhs_mfma.h"   // StagePick: per-stage constants as SGPR selects
 
 namespace ddd {
 namespace stream {
@@ -227,16 +228,25 @@ __global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepA
   const int i0 = threadIdx.x * kStepPer;
   const int s0 = (i0 / n) * n;
   const int pos0 = i0 - s0;
-  const float h = (float)a.dt;
+  // a[s] h / b[s] h from StageConsts (host-formed, the same float products): indexing the
+  // by-value tableau with the stage made the compiler copy it to SCRATCH -- a 32-byte frame
+  // per thread, written at every launch: the 72 MiB of WRITE_SIZE against 64 MiB of state
+  // in round 4's counters (profiles/r4_rocprof_summary.txt "stream_step")
+  const mfma::StagePick<float> ah(a.sc.ah), bh(a.sc.bh);
   const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   const auto fetch = [&](int t, float4 (&v)[kStepQuads]) {
     const long base = (long)t * pts;
     const long rest = total - base;
     const int live = rest < (long)pts ? (int)rest : pts;
+    // (if / else, not `cond ? *ptr : zero4`: both arms of that conditional are lvalues, so
+    // it selected between a global address and the ADDRESS of zero4 -- which put zero4 in a
+    // scratch slot, written by every thread of every launch (the 8 MiB of WRITE_SIZE above
+    // the 64 MiB of state in round 4's counters), and turned the load into a flat one)
 #pragma unroll
-    for (int k = 0; k < kStepQuads; ++k)
-      v[k] = (t < tiles && i0 < live)
-                 ? *reinterpret_cast<const float4*>(a.y_in + base + i0 + 4 * k) : zero4;
+    for (int k = 0; k < kStepQuads; ++k) {
+      v[k] = zero4;
+      if (t < tiles && i0 < live) v[k] = *reinterpret_cast<const float4*>(a.y_in + base + i0 + 4 * k);
+    }
   };
   float4 next[kStepQuads];
   fetch((int)blockIdx.x, next);
@@ -259,18 +269,21 @@ __global__ __launch_bounds__(kThreads) void fixed_step_kernel(DevParams p, StepA
     for (int s = 0; s < a.tab.stages; ++s) {
       __syncthreads();   // the tile holds this stage's input
       float r[kStepPer];
+      if (mine) {
+        step_stage<kEq, kG>(p, tile, s0, pos0, n, r);
+      } else {
 #pragma unroll
-      for (int q = 0; q < kStepPer; ++q) r[q] = 0.0f;
-      if (mine) step_stage<kEq, kG>(p, tile, s0, pos0, n, r);
+        for (int q = 0; q < kStepPer; ++q) r[q] = 0.0f;
+      }
       const bool last = s + 1 == a.tab.stages;
-      if (a.tab.b[s] != 0.0f || last) {
-        const float c2 = a.tab.b[s] * h;
+      if (((a.sc.b_nonzero >> s) & 1) || last) {
+        const float c2 = bh.at(s);
 #pragma unroll
         for (int q = 0; q < kStepPer; ++q) ynew[q] = ynew[q] + c2 * r[q];
       }
       if (!last) {
         __syncthreads();   // every stencil read of this stage is done
-        const float c1 = a.tab.a[s + 1] * h;
+        const float c1 = ah.at(s + 1);
 #pragma unroll
         for (int k = 0; k < kStepQuads; ++k)
           *reinterpret_cast<float4*>(tile + i0 + 4 * k) =

@@ -173,8 +173,10 @@ typedef struct ddd_model ddd_model;
  * filter_size <= 64 (not both > 5 and > 32): the f32-MFMA kernels -- 5 taps x 32 filters with
  * per-equation kernels, 7 x 32 / 5 x 64 / 3 x 32 with streamed weights, nets in between
  * embedded exactly with zero weights; num_layers = 1 with coefficient output: affine
- * coefficients folded here, evaluated on the VALU route of the same kernels; everything
- * else (larger nets or grids, num_points < 8, stencils > 12 points): the generic kernel.
+ * coefficients folded here, evaluated by the lane == grid point kernel (persistent
+ * launches, num_points | 64, float32 state: "valu_f32_lean") or on the VALU route of the
+ * MFMA-path kernels; everything else (larger nets or grids, num_points < 8, stencils > 12
+ * points): the generic kernel.
  */
 DDD_API int ddd_model_create(const ddd_config* cfg, const float* weights,
                      size_t n_weights, const float* nullspace,
@@ -202,7 +204,11 @@ DDD_API int ddd_baseline_create(const ddd_config* cfg, const float* stencils,
  * Non-flux equations only (DDD_EQ_BURGERS, DDD_EQ_KDV, DDD_EQ_KS:
  * integrate.py:346-347), N <= 2048.  Only the *_f64 entry points below accept
  * such a model; it carries no forcing (finalize_time_derivative stays on the
- * host, where the reference evaluates it in float64). */
+ * host, where the reference evaluates it in float64).
+ * num_points a power of two >= 512: the same operators run as an in-LDS float64 FFT
+ * (multipliers = the DFT of `kernels`, formed here in extended precision, so the
+ * conventions of the call that produced the kernels carry over); smaller grids: the
+ * O(N^2) circulant products. */
 DDD_API int ddd_spectral_create(const ddd_config* cfg, const double* kernels,
                         size_t n_kernels, ddd_model** out);
 
@@ -408,8 +414,9 @@ DDD_API int ddd_polynomial_accuracy_apply(const float* inputs, const float* null
 
 /* ---- introspection -------------------------------------------------------*/
 DDD_API int ddd_set_kernel(ddd_model* model, int kernel_kind);
-/* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256", "generic",
- * "stream_fixed" (fixed stencils, one launch per substep) or "spectral_f64":
+/* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r256", "generic", "valu_f32_lean" (fixed
+ * stencils / one-layer nets, persistent launch: lane == grid point, no matrix work),
+ * "stream_fixed" (fixed stencils, one launch per substep or step) or "spectral_f64":
  * the kernel family and workgroup geometry of the most recent launch on this
  * handle (the automatic choice depends on the batch size and launch mode). */
 DDD_API const char* ddd_kernel_name(const ddd_model* model);

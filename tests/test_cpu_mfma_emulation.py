@@ -146,6 +146,18 @@ def test_relu_as_scaled_clamp_keeps_the_bits():
   np.testing.assert_array_equal((w * up) * (h * dn), w * h)
 
 
+def test_fast_tanh_formula_stays_within_2e7():
+  """rhs_mfma.h::fast_tanh: sign(x) (1 - t) / (1 + t), t = exp2(-2 log2(e) |x|), in float32
+  with correctly rounded exp2 / reciprocal (the hardware's are within one ulp: <= 1e-7 more)."""
+  x = np.concatenate([np.linspace(-12, 12, 400001), np.logspace(-8, 1.2, 50000),
+                      -np.logspace(-8, 1.2, 50000), [0.0, np.inf, -np.inf]]).astype(np.float32)
+  t = np.exp2(np.abs(x) * np.float32(-2.885390081777927)).astype(np.float32)
+  q = ((np.float32(1) - t) * (np.float32(1) / (np.float32(1) + t)).astype(np.float32))
+  got = np.copysign(q.astype(np.float32), x)
+  assert np.abs(got - np.tanh(x.astype(np.float64))).max() < 2e-7
+  assert got[-2] == 1.0 and got[-1] == -1.0 and got[-3] == 0.0
+
+
 @pytest.mark.parametrize('n,num_layers,c_out', [(64, 3, 9), (32, 3, 11),
                                                  (48, 2, 8), (256, 4, 16),
                                                  (100, 3, 9)])
