@@ -76,7 +76,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 MFMA = f32 vector peak
 PEAK_HBM_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E spec peak
 MEASURED_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md: float4 copy, the achievable HBM rate
-TRAFFIC_TABLES = ('r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json',
+TRAFFIC_TABLES = ('r5_hbm_traffic.json', 'r4_hbm_traffic.json', 'r3_hbm_traffic.json', 'r2_hbm_traffic.json',
                   'r1_hbm_traffic.json')   # newest first
 
 

@@ -849,10 +849,13 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, kAbid, 0);
 }
 
-template <int NG, int Q0, int NW, int... J>
+// (kAcc accumulator chains: NG, one per channel group -- or TWO for a single group, whose lone
+// dependent chain runs at 13.2 cycles per MFMA instead of 8.5: the direct heads, model.py:551-615,
+// sum the two halves of the reduction at the end)
+template <int NG, int Q0, int NW, int kAcc, int... J>
 __device__ __forceinline__ void fin4_mfmas(const float (&w)[NW], const f32x4& b,
-                                           f32x4 (&acc)[NG], std::integer_sequence<int, J...>) {
-  ((acc[J % NG] = mfma4<(Q0 + J) % 16>(w[(Q0 + J) / 16], b[J / NG], acc[J % NG])), ...);
+                                           f32x4 (&acc)[kAcc], std::integer_sequence<int, J...>) {
+  ((acc[J % kAcc] = mfma4<(Q0 + J) % 16>(w[(Q0 + J) / 16], b[J / NG], acc[J % kAcc])), ...);
 }
 
 template <int NG>
@@ -865,47 +868,47 @@ constexpr int kFin4Ahead = 2;   // operand groups in flight ahead of the MFMAs
 
 // (TW: the tower -- K taps x C channels: K C / 4 operand groups of four channels,
 // C / 4 per tap row)
-template <int NG, int OG, class TW>
+template <int NG, int OG, class TW, int kAcc>
 __device__ __forceinline__ void fin4_step(const char* __restrict__ in, const int (&off)[TW::kK],
                                           const float (&w)[fin4_regs_t<TW>(NG)],
-                                          f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG]) {
+                                          f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[kAcc]) {
   constexpr int kNext = OG + kFin4Ahead;
   constexpr int kPerTap = TW::kC / 4;
   if constexpr (kNext < TW::kOperandGroups)
     buf[kNext % (kFin4Ahead + 1)] =
         *reinterpret_cast<const f32x4*>(in + off[kNext / kPerTap] + 16 * (kNext % kPerTap));
-  fin4_mfmas<NG, OG * 4 * NG>(w, buf[OG % (kFin4Ahead + 1)], acc,
-                              std::make_integer_sequence<int, 4 * NG>{});
+  fin4_mfmas<NG, OG * 4 * NG, fin4_regs_t<TW>(NG), kAcc>(w, buf[OG % (kFin4Ahead + 1)], acc,
+                                                         std::make_integer_sequence<int, 4 * NG>{});
   if constexpr (kNext < TW::kOperandGroups) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
   __builtin_amdgcn_sched_group_barrier(0x008, 4 * NG, 0);                        // MFMAs
 }
 
-template <int NG, class TW, int... OG>
+template <int NG, class TW, int kAcc, int... OG>
 __device__ __forceinline__ void fin4_run(const char* __restrict__ in, const int (&off)[TW::kK],
                                          const float (&w)[fin4_regs_t<TW>(NG)],
-                                         f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[NG],
+                                         f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[kAcc],
                                          std::integer_sequence<int, OG...>) {
-  (fin4_step<NG, OG, TW>(in, off, w, buf, acc), ...);
+  (fin4_step<NG, OG, TW, kAcc>(in, off, w, buf, acc), ...);
 }
 
 // `off`: LDS byte offsets (row * kHS * 4) of the lane's tap rows.
-template <int NG, class TW = DefaultTower>
+template <int NG, class TW = DefaultTower, int kAcc = NG>
 __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
                                              const float (&w)[fin4_regs_t<TW>(NG)],
-                                             const int (&off)[TW::kK], f32x4 (&acc)[NG]) {
+                                             const int (&off)[TW::kK], f32x4 (&acc)[kAcc]) {
   const char* __restrict__ in = reinterpret_cast<const char*>(in_f);
   constexpr int kPerTap = TW::kC / 4;
   f32x4 buf[kFin4Ahead + 1];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int g = 0; g < kAcc; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int og = 0; og < kFin4Ahead; ++og)
     buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / kPerTap] + 16 * (og % kPerTap));
   __builtin_amdgcn_sched_group_barrier(0x100, kFin4Ahead, 0);
-  fin4_run<NG, TW>(in, off, w, buf, acc, std::make_integer_sequence<int, TW::kOperandGroups>{});
+  fin4_run<NG, TW, kAcc>(in, off, w, buf, acc, std::make_integer_sequence<int, TW::kOperandGroups>{});
   // bias row: k = K C against a constant 1
-  fin4_mfmas<NG, (TW::kFinK - 1) * NG>(w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc,
-                                       std::make_integer_sequence<int, NG>{});
+  fin4_mfmas<NG, (TW::kFinK - 1) * NG, fin4_regs_t<TW>(NG), kAcc>(
+      w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc, std::make_integer_sequence<int, NG>{});
 }
 
 // Wavefronts per SIMD the kernels are compiled for: two, except the four-wave groups of the
@@ -1295,10 +1298,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
             float w1[fin4_regs_t<TW>(1)];
 #pragma unroll
             for (int s2 = 0; s2 < fin4_regs_t<TW>(1); ++s2) w1[s2] = wf4[s2];
-            f32x4 acc1[1];
-            final_layer4<1, TW>(in, w1, off4, acc1);
+            f32x4 acc1[2];   // two accumulator chains over alternate reduction steps, summed here
+            final_layer4<1, TW, 2>(in, w1, off4, acc1);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) net[r4] = acc1[0][r4];
+            for (int r4 = 0; r4 < 4; ++r4) net[r4] = acc1[0][r4] + acc1[1][r4];
           }
           done = head;
           // pairs: group index 2 j (head 0) or 2 j + 1 (odd head): compile-time slots
