@@ -55,7 +55,7 @@ def pmc(tag, pattern):
 
 
 P('# Round 5 -- measurement run (profiles/tools/collect_r5.sh, one gpurun call, 1 x MI355X)')
-P('# raw outputs: gpurun_out/r5prof (scratch); this file: profiles/tools/summarize_r4.py\n')
+P('# raw outputs: gpurun_out/r5prof (scratch); this file: profiles/tools/summarize_r5.py\n')
 P(open(O + '/smoke.txt').read().strip() + '\n')
 
 line = json.load(open(O + '/bench_default.json'))
