@@ -478,31 +478,40 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     const bool projected = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao > 0;
     const bool direct_coeffs = dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0;
     // the kernels' folded epilogue exists for two derivatives and 6..8 stencil points
-    const bool fold_shape = dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
-    bool can_fold = projected && fold_shape && !g_debug.no_fold;
+    // (default flavour: channel G d + g of 16) and -- always -- for the wide flavour's
+    // coefficient nets (channel wide_slot(G) d + g of 36, up to three derivatives: the wide
+    // kernels have no projection code at all)
+    const bool wide_fold = m->wide && dp.target == ddd::TARGET_COEFFICIENTS;
+    const int slot = wide_fold ? ddd::mfma::wide_slot(dp.G) : dp.G;
+    const int fold_cols = wide_fold ? ddd::mfma::flavour_net_channels(true) : 16;
+    const bool fold_shape = wide_fold ? dp.D <= ddd::mfma::kWideDerivs
+                                      : dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
+    bool can_fold = projected && fold_shape && (!g_debug.no_fold || wide_fold);
     if (direct_coeffs && fold_shape) {
       // the net emits the D x G coefficients themselves (model.py:460-475) in
       // exactly the folded layer's channel order: nothing to project
       can_fold = true;
-      wf.assign((size_t)kc * 16, 0.0f);
-      bf.assign(16, 0.0f);
-      for (int c = 0; c < dp.D * dp.G; ++c) {
-        for (int row = 0; row < kc; ++row)
-          wf[(size_t)row * 16 + c] = w_nat[(size_t)row * dp.C_out + c];
-        bf[c] = b_nat[c];
-      }
-    } else if (can_fold) {
-      wf.assign((size_t)kc * 16, 0.0f);
-      bf.assign(16, 0.0f);
+      wf.assign((size_t)kc * fold_cols, 0.0f);
+      bf.assign(fold_cols, 0.0f);
       for (int d = 0; d < dp.D; ++d)
         for (int g = 0; g < dp.G; ++g) {
-          const int oc = dp.G * d + g;
+          const int c = dp.G * d + g, oc = slot * d + g;
+          for (int row = 0; row < kc; ++row)
+            wf[(size_t)row * fold_cols + oc] = w_nat[(size_t)row * dp.C_out + c];
+          bf[oc] = b_nat[c];
+        }
+    } else if (can_fold) {
+      wf.assign((size_t)kc * fold_cols, 0.0f);
+      bf.assign(fold_cols, 0.0f);
+      for (int d = 0; d < dp.D; ++d)
+        for (int g = 0; g < dp.G; ++g) {
+          const int oc = slot * d + g;
           for (int row = 0; row < kc; ++row) {
             double acc = 0.0;
             for (int j = 0; j < dp.in_size[d]; ++j)
               acc += (double)w_nat[(size_t)row * dp.C_out + dp.in_start[d] + j] *
                      (double)dp.ns8[dp.in_start[d] + j][g];
-            wf[(size_t)row * 16 + oc] = (float)acc;
+            wf[(size_t)row * fold_cols + oc] = (float)acc;
           }
           // bias row of the folded layer: the accuracy layer's standard
           // coefficients + the projected conv bias, rounded once
@@ -521,7 +530,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     auto pack4 = [&](int groups, bool folded, bool renumber) {
       const float* w = folded ? wf.data() : w_nat;
       const float* b = folded ? bf.data() : b_nat;
-      const int cout_n = folded ? 16 : dp.C_out;
+      const int cout_n = folded ? fold_cols : dp.C_out;
       const int n_ch = folded ? dp.D * dp.G : dp.C_out;
       std::vector<float> packed4((size_t)ddd::mfma::fin4_regs(4) * 64, 0.0f);
       for (int k = 0; k < ddd::mfma::kFin4K; ++k)
@@ -548,15 +557,17 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
     // polynomial_accuracy_order = 0 has nothing to project.
     const auto issue_cost = [](int groups) { return groups == 1 ? 13.2 : 8.1 * groups; };
     const int groups_rt_plain = (dp.C_out + 3) / 4;
-    const int groups_rt_folded = (dp.D * dp.G + 3) / 4;
-    const bool fold_rt = can_fold && (direct_coeffs || issue_cost(groups_rt_folded) <=
-                                                           issue_cost(groups_rt_plain) + 2.5);
+    const int groups_rt_folded = ((dp.D - 1) * slot + dp.G + 3) / 4;
+    const bool fold_rt = can_fold && (direct_coeffs || wide_fold ||
+                                      issue_cost(groups_rt_folded) <=
+                                          issue_cost(groups_rt_plain) + 2.5);
+    if (wide_fold && !fold_rt) return DDD_ERR_UNSUPPORTED;   // (decide_mfma admits only what folds)
     m->dp.folded = fold_rt ? 1 : 0;
     m->dp.rt_groups = fold_rt ? groups_rt_folded : groups_rt_plain;
     {
       const float* w = fold_rt ? wf.data() : w_nat;
       const float* b = fold_rt ? bf.data() : b_nat;
-      const int cout_n = fold_rt ? 16 : dp.C_out;
+      const int cout_n = fold_rt ? fold_cols : dp.C_out;
       // layout: the head chunk (rt_head_groups: 0, 1 or 3 groups, fin4_regs(head)
       // rows), then the pairs (fin4_regs(2) rows each); + slack so that the
       // kernels' fixed-size first fetch (fin4_regs(3) rows) stays inside
@@ -600,7 +611,7 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
       {
         const float* w = m->spec_folded ? wf.data() : w_nat;
         const float* b = m->spec_folded ? bf.data() : b_nat;
-        const int cout_n = m->spec_folded ? 16 : dp.C_out;
+        const int cout_n = m->spec_folded ? fold_cols : dp.C_out;
         const int n_ch = m->spec_folded ? dp.D * dp.G : dp.C_out;
         const int groups = m->dp.fin4_groups, na = (groups + 1) / 2;
         const int chunk_rows = ddd::mfma::fin4_regs(2);
@@ -704,7 +715,12 @@ void decide_mfma(ddd_model* m) {
     if (dp.K > 7) no("kernel_size > 7");
     if (dp.K > 5 && dp.F > 32) no("kernel_size > 5 together with filter_size > 32");
     if (dp.L < 2) no("fewer than 2 conv layers");
-    if (dp.C_out > ddd::kChWide) no("more than 24 output channels");
+    // the wide flavour folds every coefficient net into its output layer (pack_mfma_weights):
+    // three derivatives' worth of register slots; the projection tables hold 24 net channels
+    if (wide && dp.target == ddd::TARGET_COEFFICIENTS && dp.D > ddd::mfma::kWideDerivs)
+      no("wide stencils / > 16 output channels with four derivatives");
+    if (dp.C_out > ddd::kChWide && !(wide && dp.target == ddd::TARGET_COEFFICIENTS && dp.pao <= 0))
+      no("more than 24 output channels");
     // stencils > 8 points / > 16 channels exist on the 5 x 32 tower only (wide flavour)
     if (wide && m->tower_k == 3) m->tower_k = 5;
     if (wide && m->big()) no("wide stencils / > 16 output channels with a tower other than 5 x 32");
@@ -1362,7 +1378,7 @@ int ddd_model_create(const ddd_config* cfg, const float* weights, size_t n_weigh
       const bool fold_shape = dp.D <= 2 && dp.G >= 6 && dp.G <= ddd::kGMax && !m->wide;
       rc = upload_padded_tables(m, projected ? nullspace : nullptr, projected ? bias : nullptr,
                                 dp.target == ddd::TARGET_COEFFICIENTS && !projected &&
-                                    !fold_shape);
+                                    !fold_shape && !m->wide);
       if (!rc) {
         // (the generic kernel keeps the model's own K, F and weights: a model that
         // falls back to it -- N > 256, ddd_set_kernel(generic) -- never runs the

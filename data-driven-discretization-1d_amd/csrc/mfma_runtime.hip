@@ -31,10 +31,10 @@ void integrate_wide_unit<DDD_RT_ROWS, DDD_RT_F64>(bool hoist, const DevParams& p
                                                   hipStream_t stream) {
   const dim3 grid(blocks), block(DDD_RT_ROWS);
   if (hoist)
-    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, true, -1, false, true>),
+    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, true, -1, mfma::kTraceByDefault, true>),
                        grid, block, 0, stream, p, a);
   else
-    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, false, -1, false, true>),
+    hipLaunchKernelGGL((mfma::integrate_kernel<DDD_RT_ROWS, 64, RtState, false, -1, mfma::kTraceByDefault, true>),
                        grid, block, 0, stream, p, a);
 }
 #if !DDD_RT_F64

@@ -27,6 +27,7 @@
 // f32-input MFMA is bit-for-bit an fmaf chain in k order, so the arithmetic is
 // IEEE float32 like the reference's TF graph; only the summation order differs.
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "dev_params.h"
@@ -43,11 +44,26 @@ constexpr int kFin4K = kKW * kF + 1;   // output layer on 4x4x1 MFMAs: 160 reduc
 constexpr int kTrigMax = 12;     // 2 * (distinct wavenumbers) kept per lane
 // Flavours of the run-time-parameterised kernels (template parameter kWide):
 // default: stencils <= 8 points, <= 16 output channels; wide: <= 12 points,
-// <= 24 channels, projection always in the epilogue (never folded).
+// <= 24 channels of the net, projection always folded into the output layer.
 __host__ __device__ constexpr int flavour_stencil(bool wide) { return wide ? kGWide : kGMax; }
 __host__ __device__ constexpr int flavour_channels(bool wide) { return wide ? kChWide : kChMax; }
-// projection tables in LDS: 4 bias rows + one null-space row per output channel
-__host__ __device__ constexpr int tab_rows(bool wide) { return 4 + flavour_channels(wide); }
+// Output channels the kernels carry in registers.  The wide flavour's output layer is ALWAYS
+// folded (round 5): it emits coefficient g of derivative d as channel kGWide d + g -- slots
+// of twelve, three channel groups per derivative, D <= 3 --, so the epilogue's register
+// indices are compile-time constants and there is no projection left to run there.
+constexpr int kWideDerivs = 3;
+__host__ __device__ constexpr int flavour_net_channels(bool wide) {
+  return wide ? kWideDerivs * kGWide : kChMax;
+}
+// ... coefficient g of derivative d = channel wide_slot(G) d + g: slots of 8 for stencils
+// of up to 8 points, of exactly G above (27 channels = 7 channel groups for 9 points and
+// three derivatives, where slots of 12 would issue 9).
+__host__ __device__ constexpr int wide_slot(int G) { return G <= kGMax ? kGMax : G; }
+// projection tables in LDS: 4 bias rows + one null-space row per output channel (default
+// flavour; the wide one has nothing to project and stages the bias rows -- the fixed
+// stencils -- only: with the 24 null-space rows its 64-row workgroups took 20 808 bytes,
+// seven to a CU instead of eight, one SIMD in four left with a single wavefront)
+__host__ __device__ constexpr int tab_rows(bool wide) { return wide ? 4 : 4 + flavour_channels(false); }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1061,7 +1077,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // issue DevParams::rt_groups live groups two by two (w_final4_rt)
   constexpr int kNG = kSpec ? spec_fin_groups(kSpec ? kEq : 0) : 2;
   constexpr int kGW = flavour_stencil(kWide);    // stencil columns carried
-  constexpr int kCh = flavour_channels(kWide);   // output channels carried
+  constexpr int kCh = flavour_net_channels(kWide);   // output channels carried
   static_assert(!(kSpec && kWide), "the per-equation kernels have no wide flavour");
   static_assert(TW::kDefault || (!kSpec && !kWide && !kHoist && kWR == 64),
                 "towers other than 5 taps x 32 channels: run-time-parameterised kernels only");
@@ -1395,7 +1411,27 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   for (int d = 0; d < kMaxDerivs; ++d)
 #pragma unroll
     for (int q = 0; q < kGW / 2; ++q) cf2[d][q] = f32x2{0.0f, 0.0f};
-  if (!fixed && folded && !kWide) {
+  if (kWide) {
+    // wide flavour: the output layer emits the coefficients themselves, wide_slot(G)
+    // channels per derivative (capi.hip: pack_mfma_weights folds the projection and the
+    // accuracy bias for every wide model).  One wave-uniform branch over the slot width
+    // makes every register index a compile-time constant; nothing is left to project.
+    if (!fixed && target == TARGET_COEFFICIENTS) {
+      const auto take = [&](auto slot_c) {
+        constexpr int kSlot = decltype(slot_c)::value;
+#pragma unroll
+        for (int d = 0; d < kWideDerivs; ++d)
+#pragma unroll
+          for (int g = 0; g < kSlot; ++g)
+            if (kSlot * d + g < kCh && g < kGW) CF(d, g) = net[(kSlot * d + g) % kCh];
+      };
+      if (nG <= kGMax) take(std::integral_constant<int, kGMax>{});
+      else if (nG == 9) take(std::integral_constant<int, 9>{});
+      else if (nG == 10) take(std::integral_constant<int, 10>{});
+      else if (nG == 11) take(std::integral_constant<int, 11>{});
+      else take(std::integral_constant<int, 12>{});
+    }
+  } else if (!fixed && folded) {
     // the output layer already applied the projection (or the net emits the
     // coefficients themselves, polynomial_accuracy_order 0): channel G d + g,
     // D <= 2.  Register indices must be compile-time: the run-time kernels
@@ -1502,7 +1538,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
         dv[d] = net[d];
         continue;
       }
-      if (!folded || kWide) {   // (folded: the bias rides in the output layer's bias row)
+      if (fixed || (!folded && !kWide)) {   // (folded / wide nets: the bias rides in the output layer's bias row)
 #pragma unroll
         for (int q = 0; q < kGW / 2; ++q) {
           const float2 bq = *reinterpret_cast<const float2*>(sm.tab + d * kGW + 2 * q);

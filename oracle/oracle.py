@@ -109,10 +109,26 @@ _NONLINEARITIES = {
 }
 
 
-def conv1d_periodic_layer(inputs, kernel, bias, activation=None, center=True):
-  """layers.py:103-137 with dilation 1, stride 1."""
-  k_size = np.asarray(kernel).shape[0]
-  out = conv1d_valid(pad_periodic(inputs, k_size - 1, center), kernel, bias)
+def conv1d_periodic_layer(inputs, kernel, bias, activation=None, center=True, strides=1,
+                          dilation_rate=1):
+  """layers.py:103-137: pad (K - 1) * dilation_rate periodically, then
+  tf.layers.conv1d(padding='valid', strides, dilation_rate):
+    out[b, i, f] = b_f + sum_{k, c} W[k, c, f] padded[b, i * strides + k * dilation_rate, c],
+    i < ceil(N / strides)."""
+  kernel = np.asarray(kernel)
+  k_size = kernel.shape[0]
+  padded = pad_periodic(inputs, (k_size - 1) * dilation_rate, center)
+  if strides == 1 and dilation_rate == 1:
+    out = conv1d_valid(padded, kernel, bias)
+  else:
+    n = np.asarray(inputs).shape[1]
+    n_out = -(-n // strides)
+    out = np.zeros((padded.shape[0], n_out, kernel.shape[2]), F32)
+    for k in range(k_size):
+      rows = padded[:, k * dilation_rate:k * dilation_rate + (n_out - 1) * strides + 1:strides, :]
+      out = out + np.einsum('bxc,cf->bxf', rows.astype(F32), kernel[k].astype(F32)).astype(F32)
+    if bias is not None:
+      out = (out + np.asarray(bias, F32)).astype(F32)
   if activation is not None:
     out = _NONLINEARITIES[activation](out).astype(F32)
   return out

@@ -9,11 +9,17 @@ if 'no_spec' in sys.argv:   # trace the run-time-parameterised kernel instead of
 for item in [a for a in sys.argv if a.startswith('ablate=')]:   # skip phases (WRONG results): 1 forcing, 2 projection, 4 output layer, 16 input layer
     ddd1d_amd._lib.debug_set_option('ablate', int(item.split('=')[1]))
     sys.argv.remove(item)
+eq_name, extra = 'burgers', {}
+for item in [a for a in sys.argv if a.startswith('eq=')]:       # eq=ks: another equation (run-time kernels)
+    eq_name = item.split('=')[1]; sys.argv.remove(item)
+for item in [a for a in sys.argv if a.startswith('hp=')]:       # hp={"coefficient_grid_min_size": 9}
+    extra = json.loads(item[3:]); sys.argv.remove(item)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-hp = ddd1d_amd.create_hparams('burgers', conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}))
+hp = ddd1d_amd.create_hparams(eq_name, conservative=True, resample_factor=8, equation_kwargs=json.dumps({'num_points': 512}), **extra)
 _, eq = equations.from_hparams(hp)
 m = model_lib.LearnedStencilModel(eq, hp)
-m.set_forcing(model_lib.batched_forcing_parameters(range(B), nparams=20))
+if eq_name == 'burgers':
+    m.set_forcing(model_lib.batched_forcing_parameters(range(B), nparams=20))
 y0 = torch.randn(B, 64, device='cuda') * 0.3
 trace = torch.zeros(B * 256, dtype=torch.int64, device='cuda')
 ddd1d_amd._lib.debug_set_option('trace_ptr', trace.data_ptr())

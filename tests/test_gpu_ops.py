@@ -71,6 +71,30 @@ def test_conv1d_periodic_random(n, cin, cout, k, center):
   assert rel_err(got, want) < 2e-6
 
 
+@pytest.mark.parametrize('n,cin,cout,k,strides,dilation,center', [
+    (64, 3, 5, 5, 1, 2, True), (64, 3, 5, 5, 1, 3, False), (37, 2, 4, 3, 1, 4, True),
+    (64, 3, 5, 5, 2, 1, True), (37, 2, 4, 4, 3, 1, True), (16, 1, 1, 2, 4, 1, False),
+])
+def test_conv1d_periodic_strides_and_dilation(n, cin, cout, k, strides, dilation, center):
+  """layers.py:103-137: strides / dilation_rate of conv1d_periodic_layer (never used by the
+  reference's models, part of its layer API): [batch, ceil(N / strides), filters]."""
+  rs = np.random.RandomState(n + k + strides + dilation)
+  x = rs.randn(2, n, cin).astype(np.float32)
+  w = rs.randn(k, cin, cout).astype(np.float32)
+  b = rs.randn(cout).astype(np.float32)
+  got = layers.conv1d_periodic_layer(x, w, b, activation='tanh', strides=strides,
+                                     dilation_rate=dilation, center=center).cpu().numpy()
+  want = oracle.conv1d_periodic_layer(x, w, b, 'tanh', center=center, strides=strides,
+                                      dilation_rate=dilation)
+  assert got.shape == want.shape == (2, -(-n // strides), cout)
+  assert rel_err(got, want) < 2e-6
+  if dilation == 1:
+    plain = layers.nn_conv1d_periodic(x, w, stride=strides, center=center).cpu().numpy()
+    assert plain.shape == (2, -(-n // strides), cout)
+  with pytest.raises(ValueError, match='conjunction'):
+    layers.conv1d_periodic_layer(x, w, b, strides=2, dilation_rate=2)
+
+
 @pytest.mark.parametrize('activation', ['relu', 'relu6', 'tanh', 'softplus', 'elu'])
 def test_activations(activation):
   rs = np.random.RandomState(7)
