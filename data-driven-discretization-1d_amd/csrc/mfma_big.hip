@@ -31,7 +31,7 @@ template <>
 void integrate_big_unit<DDD_BIG_K, DDD_BIG_CB, DDD_BIG_ROWS, DDD_BIG_KIND == 2>(
     const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream) {
   hipLaunchKernelGGL(
-      (mfma::integrate_kernel<DDD_BIG_ROWS, 64, BigState, false, -1, false, false, BigTower>),
+      (mfma::integrate_kernel<DDD_BIG_ROWS, 64, BigState, false, -1, mfma::kTraceByDefault, false, BigTower>),
       dim3(blocks), dim3(DDD_BIG_ROWS), 0, stream, p, a);
 }
 #elif DDD_BIG_KIND == 1

@@ -141,7 +141,7 @@ constexpr int adaptive_lean() {
 }
 
 template <int kRows, int kWR, bool kHoist, int kEq, bool kWide = false, class TW = DefaultTower>
-__global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) void adaptive_kernel(
+__global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>())) void adaptive_kernel(
     DevParams p, AdaptiveArgs a) {
   __shared__ Shared<kRows, kWR, kWide, TW> sm;
   __shared__ AdaptiveShared<kRows> as;
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   const int tid = (int)threadIdx.x;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, (int)blockIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
+  // (no resident tower weights here: the controller state needs the registers -- with them
+  // the streamed-tower adaptive kernels spill 3-16 VGPRs)
+  const bool fast_frc = launch_setup<kRows, kWR, kHoist, false>(p, sm, ln, a.batch, res);
   // sample whose (sample, mode) pair this lane evaluates in forcing phase 1
   const int frc_sl = (fast_frc && tid < (kRows / p.N) * p.P)
                          ? row_sample(tid, p.inv_P) : 0;

@@ -107,6 +107,16 @@ __host__ __device__ constexpr int fin4_regs_t(int groups) { return (TW::kFinK * 
 // no cross-wave dependency, wavefronts free-run and eight workgroups share a
 // CU).  Sizes are chosen so that 160 KiB of LDS hold 2 x 256-row or 8 x 64-row
 // workgroups.
+// A/B (profiles/r5_ablation.txt): the one-wave kernels of the 3-tap tower at THREE wavefronts
+// per SIMD (single activation buffer: 11.9 KB of LDS, 168 VGPRs, two resident weight groups)
+// measured below two wavefronts with the whole hidden layer resident (241 VGPRs): 62.9 vs
+// 64.4 % at 4 096 samples, 39.7 vs 50.5 % with one launch per substep.
+#ifndef DDD_K3_WAVES
+#define DDD_K3_WAVES 2
+#endif
+#ifndef DDD_K3_RESIDENT_ALL
+#define DDD_K3_RESIDENT_ALL (DDD_K3_WAVES == 2)
+#endif
 template <int kRows, int kWR = 64, bool kWide = false, class TW = DefaultTower>
 struct Shared {
   static constexpr int kPmMax = kRows;          // (sample, mode) pairs staged
@@ -116,7 +126,7 @@ struct Shared {
   // wavefront execute in order), so the layer can be written in place -- 20 KB instead of
   // 37 KB per group: eight groups per CU = two wavefronts per SIMD instead of one.  hB then
   // only holds the second half of the per-row cos / sin table (four floats per row).
-  static constexpr bool kSingleBuffer = kRows == kWR && TW::kCB == 2;
+  static constexpr bool kSingleBuffer = kRows == kWR && (TW::kCB == 2 || (TW::kK == 3 && DDD_K3_WAVES == 3));
   static constexpr int kHBStride = kSingleBuffer ? 4 : TW::kHS;
   static constexpr int kHBPad = kSingleBuffer ? 0 : TW::kC;      // float offset of a row's padding in hB
   float hA[kRows * TW::kHS];
@@ -134,8 +144,8 @@ static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU")
 static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
 static_assert(8 * sizeof(Shared<64>) <= 158 * 1024, "2 x four-group workgroups per CU, with slack");
 static_assert(sizeof(Shared<64, 32>) <= 40 * 1024, "4 x two-wave workgroups per CU");
-static_assert(sizeof(Shared<64, 64, true>) <= 22 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
-              "wide flavour: 7 x 64-row / 2 x 256-row workgroups per CU");
+static_assert(sizeof(Shared<64, 64, true>) <= 20 * 1024 && sizeof(Shared<256, 64, true>) <= 80 * 1024,
+              "wide flavour: 8 x 64-row / 2 x 256-row workgroups per CU");
 static_assert(sizeof(Shared<64, 64, false, Tower<5, 2>>) <= 20 * 1024 &&
               sizeof(Shared<256, 64, false, Tower<5, 2>>) <= 160 * 1024,
               "64-filter towers: 8 x 64-row (single activation buffer) / 1 x 256-row workgroups per CU");
@@ -734,6 +744,17 @@ __device__ __forceinline__ void input_layer_big(const DevParams& p, const Lane& 
 // ds_read_b128 of activations per tile.  Weights are requested kStreamAhead groups
 // (8-16 MFMAs = 512-1024 cycles each) before their MFMAs, activations one group ahead.
 constexpr int kStreamAhead = 2;
+// The FIRST hidden layer's leading weight groups stay in registers for the whole launch
+// (Resident::hw): the stream's first requests were a full L2 round trip that every evaluation
+// waited for at the input -> hidden boundary (phase trace, round 5: 3 400 cycles exposed per
+// evaluation on the 3-tap tower against 1 700 on the default tower with its resident
+// weights).  3 taps x 32 filters: the whole layer (12 float4 + bias = 49 registers, no
+// stream left); the bigger towers: as many groups as the stream runs ahead.
+template <class TW>
+__host__ __device__ constexpr int resident_groups() {
+  return TW::kDefault ? 0 : (TW::kHidGroups * TW::kCB <= 12 && DDD_K3_RESIDENT_ALL ? TW::kHidGroups : kStreamAhead);
+}
+constexpr int kResidentQuads = 12;   // float4 registers of Resident::hw
 
 template <class TW, int kT>
 struct StreamState {
@@ -752,10 +773,12 @@ __device__ __forceinline__ float4 stream_operand(const StreamState<TW, kT>& st, 
                                           128 * ((G / 4) % TW::kCB) + 16 * (G % 4));
 }
 
-template <class TW, int kT, int G>
-__device__ __forceinline__ void stream_group(StreamState<TW, kT>& st) {
+// kRes: groups 0 .. kRes - 1 come from `hw` (Resident::hw), the stream starts at group kRes
+// (its first kStreamAhead groups requested by hidden_layer_stream before group 0 is issued)
+template <class TW, int kT, int kRes, int G>
+__device__ __forceinline__ void stream_group(StreamState<TW, kT>& st, const float4* hw) {
   constexpr int kCB = TW::kCB, kG = TW::kHidGroups;
-  if constexpr (G + kStreamAhead < kG) {
+  if constexpr (G + kStreamAhead < kG && G + kStreamAhead >= kRes + kStreamAhead) {
 #pragma unroll
     for (int h = 0; h < kCB; ++h)
       st.wbuf[(G + kStreamAhead) % (kStreamAhead + 1)][h] = st.wq[((G + kStreamAhead) * kCB + h) * 64];
@@ -764,7 +787,7 @@ __device__ __forceinline__ void stream_group(StreamState<TW, kT>& st) {
 #pragma unroll
     for (int t = 0; t < kT; ++t) st.bbuf[(G + 1) & 1][t] = stream_operand<TW, kT, G + 1>(st, t);
   }
-  const float4* wg = st.wbuf[G % (kStreamAhead + 1)];
+  const float4* wg = G < kRes ? hw + G * kCB : st.wbuf[G % (kStreamAhead + 1)];
   const float4* bg = st.bbuf[G & 1];
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
@@ -783,22 +806,26 @@ __device__ __forceinline__ void stream_group(StreamState<TW, kT>& st) {
 #pragma unroll
     for (int t = 0; t < kT; ++t) st.acc[h][t] = DDD_MFMA32(wg[h].w, bg[t].w, st.acc[h][t]);
   // schedule: the requests of later groups first, then this group's MFMAs
-  if constexpr (G + kStreamAhead < kG) __builtin_amdgcn_sched_group_barrier(0x020, kCB, 0);   // VMEM reads
+  if constexpr (G + kStreamAhead < kG && G >= kRes)
+    __builtin_amdgcn_sched_group_barrier(0x020, kCB, 0);   // VMEM reads
   if constexpr (G + 1 < kG) __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);              // DS reads
   __builtin_amdgcn_sched_group_barrier(0x008, 4 * kCB * kT, 0);                              // MFMAs
 }
 
-template <class TW, int kT, int... G>
-__device__ __forceinline__ void stream_groups(StreamState<TW, kT>& st,
+template <class TW, int kT, int kRes, int... G>
+__device__ __forceinline__ void stream_groups(StreamState<TW, kT>& st, const float4* hw,
                                               std::integer_sequence<int, G...>) {
-  (stream_group<TW, kT, G>(st), ...);
+  (stream_group<TW, kT, kRes, G>(st, hw), ...);
 }
 
-template <class TW, int kWR>
+// kRes > 0: hidden layer 0 with its leading groups and bias rows resident (hw, hwb)
+template <class TW, int kWR, int kRes = 0>
 __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const Lane& ln,
                                                     int hidden_index, const float* in,
                                                     float* out,   // (may be `in`: see Shared::kSingleBuffer)
-                                                    const int (&rows)[2][TW::kK], int act) {
+                                                    const int (&rows)[2][TW::kK], int act,
+                                                    const float4* hw = nullptr,
+                                                    const float* hwb = nullptr) {
   constexpr int kT = kWR / 32, kCB = TW::kCB, kG = TW::kHidGroups;
   const int j = ln.lane & 31, half = ln.lane >> 5;
   StreamState<TW, kT> st;
@@ -820,14 +847,16 @@ __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const La
       for (int r = 0; r < 16; ++r) st.acc[h][t][r] = 0.0f;
   float wb[kCB];
 #pragma unroll
-  for (int h = 0; h < kCB; ++h) wb[h] = wbias[h * 64];
+  for (int h = 0; h < kCB; ++h) wb[h] = kRes > 0 ? hwb[h] : wbias[h * 64];
 #pragma unroll
-  for (int g = 0; g < kStreamAhead; ++g)
+  for (int g = kRes; g < kRes + kStreamAhead; ++g)
+    if (g < kG) {
 #pragma unroll
-    for (int h = 0; h < kCB; ++h) st.wbuf[g][h] = st.wq[(g * kCB + h) * 64];
+      for (int h = 0; h < kCB; ++h) st.wbuf[g % (kStreamAhead + 1)][h] = st.wq[(g * kCB + h) * 64];
+    }
 #pragma unroll
   for (int t = 0; t < kT; ++t) st.bbuf[0][t] = stream_operand<TW, kT, 0>(st, t);
-  stream_groups<TW, kT>(st, std::make_integer_sequence<int, kG>{});
+  stream_groups<TW, kT, kRes>(st, hw, std::make_integer_sequence<int, kG>{});
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
 #pragma unroll
@@ -932,8 +961,12 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
 #ifndef DDD_MIN_WAVES_AB
 #define DDD_MIN_WAVES_AB 2   // A/B (profiles/r4_ablation.txt): 1 = compile every kernel for ONE wavefront per SIMD
 #endif
-template <int kRows, int kWR, class TW>
-constexpr int min_waves() { return (TW::kCB == 2 && kRows != kWR) ? 1 : DDD_MIN_WAVES_AB; }
+template <int kRows, int kWR, class TW, bool kAdaptive = false>
+constexpr int min_waves() {
+  return (TW::kCB == 2 && kRows != kWR) ? 1
+         : (TW::kK == 3 && TW::kCB == 1 && kRows == kWR && !kAdaptive) ? DDD_K3_WAVES
+                                                                      : DDD_MIN_WAVES_AB;
+}
 
 // Kernel-lifetime registers of one lane: hoisted once per launch.
 struct Resident {
@@ -947,6 +980,9 @@ struct Resident {
   int fk_off;               // byte offset of this row's sample in Shared::fk (same kernels)
   float w_in[kInSteps];     // input-layer weights (MFMA A operand)
   float hid[kHidSteps];     // the hidden layer's weights when there is exactly one
+  float4 hw[kResidentQuads];   // streamed towers: leading weight groups [group][block] of hidden layer 0
+  float hwb[2];                // ... and its bias rows (resident_groups)
+  bool hw_valid = false;       // (a compile-time constant after inlining: set by setup_weights)
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
   float frc_mask[8];        // 1 where entry i of this lane's first 8-mode trip belongs to its run
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
@@ -1179,7 +1215,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     for (int l = 1; l < nL - 1; ++l) {
       if constexpr (!TW::kDefault) {
         group_barrier<kRows, kWR>();
-        hidden_layer_stream<TW, kWR>(p, ln, l - 1, in, out, hid_rows, act);
+        if (l == 1 && res.hw_valid)
+          hidden_layer_stream<TW, kWR, resident_groups<TW>()>(p, ln, 0, in, out, hid_rows, act,
+                                                              res.hw, res.hwb);
+        else
+          hidden_layer_stream<TW, kWR>(p, ln, l - 1, in, out, hid_rows, act);
       } else {
         if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
         group_barrier<kRows, kWR>();
@@ -1674,7 +1714,7 @@ __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln,
 }
 
 // Per-launch setup, part 1: resident registers and the tables in LDS.
-template <int kRows, int kWR, bool kHoist, bool kWide, class TW>
+template <int kRows, int kWR, bool kHoist, bool kKeepTower = true, bool kWide, class TW>
 __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               const Lane& ln, Resident& res) {
   constexpr int kThreads = kRows / kWR * 64;
@@ -1696,6 +1736,20 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
+  if constexpr (!TW::kDefault && kKeepTower) {
+    // streamed towers: the leading groups of hidden layer 0 (resident_groups)
+    constexpr int kRes = resident_groups<TW>();
+    static_assert(kRes * TW::kCB <= kResidentQuads, "Resident::hw");
+    if (!p.fixed && !p.linear_taps && p.L > 2) {
+      const float4* __restrict__ wq = reinterpret_cast<const float4*>(p.w_hidden) + opaque(ln.lane);
+#pragma unroll
+      for (int i = 0; i < kRes * TW::kCB; ++i) res.hw[i] = wq[i * 64];
+      const float* __restrict__ wbias = p.w_hidden + TW::kHidGroups * TW::kCB * 64 * 4 + opaque(ln.lane);
+#pragma unroll
+      for (int h = 0; h < TW::kCB; ++h) res.hwb[h] = wbias[h * 64];
+    }
+    res.hw_valid = true;
+  }
   if (!p.fixed && !p.linear_taps && TW::kDefault) {   // (other towers stream every layer's weights)
     load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
@@ -1767,10 +1821,10 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
 }
 
 // Per-launch setup of the persistent integrators and the one-group substep kernel.
-template <int kRows, int kWR, bool kHoist, bool kWide, class TW>
+template <int kRows, int kWR, bool kHoist, bool kKeepTower = true, bool kWide, class TW>
 __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                              const Lane& ln, int batch, Resident& res) {
-  const bool fast = setup_weights<kRows, kWR, kHoist>(p, sm, ln, res);
+  const bool fast = setup_weights<kRows, kWR, kHoist, kKeepTower>(p, sm, ln, res);
   setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast);
   return fast;
 }
