@@ -711,9 +711,9 @@ void decide_mfma(ddd_model* m) {
     // default 5 x 32); nets in between are packed zero-padded (embed_tower)
     m->tower_k = dp.K <= 3 ? 3 : dp.K <= 5 ? 5 : 7;
     m->tower_cb = dp.F <= 32 ? 1 : 2;
+    if (m->tower_cb == 2 && m->tower_k == 3) m->tower_k = 5;   // (64-filter towers: 5 and 7 taps)
     if (dp.F > 64) no("filter_size > 64");
     if (dp.K > 7) no("kernel_size > 7");
-    if (dp.K > 5 && dp.F > 32) no("kernel_size > 5 together with filter_size > 32");
     if (dp.L < 2) no("fewer than 2 conv layers");
     // the wide flavour folds every coefficient net into its output layer (pack_mfma_weights):
     // three derivatives' worth of register slots; the projection tables hold 24 net channels

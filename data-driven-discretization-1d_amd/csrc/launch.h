@@ -123,8 +123,9 @@ void adaptive_big_unit(const DevParams& p, const AdaptiveArgs& a, int blocks, hi
                                                   hipStream_t);
 #define DDD_DECLARE_BIG(K, CB) DDD_DECLARE_BIG_ROWS(K, CB, 64) DDD_DECLARE_BIG_ROWS(K, CB, 256)
 // the towers built (capi.hip: decide_mfma picks the smallest one that holds the net, embed_tower pads it;
-// 7 taps x 64 filters is not built: its unrolled layers take > 20 minutes to compile)
-#define DDD_FOR_EACH_BIG_TOWER(X) X(3, 1) X(7, 1) X(5, 2)
+// 7 taps x 64 filters runs its hidden layers as a loop over the taps -- rhs_mfma.h: Tower::kRolled --:
+// fully unrolled they took > 20 minutes to compile, rolled 2-8 minutes per kernel)
+#define DDD_FOR_EACH_BIG_TOWER(X) X(3, 1) X(7, 1) X(5, 2) X(7, 2)
 DDD_FOR_EACH_BIG_TOWER(DDD_DECLARE_BIG)
 #undef DDD_DECLARE_BIG
 #undef DDD_DECLARE_BIG_ROWS

@@ -90,6 +90,9 @@ struct Tower {
   static constexpr int kFinK = kK_ * kC + 1;        // 4x4x1 reduction steps of the output layer (+ bias)
   static constexpr int kOperandGroups = kK_ * kC / 4;   // ds_read_b128 per lane in the output layer
   static constexpr bool kDefault = kK_ == 5 && kCB_ == 1;
+  // 7 taps x 64 filters: the hidden layer runs as a loop over the taps (hidden_layer_rolled);
+  // fully unrolled its 896 MFMAs per layer and kernel took > 20 minutes to compile
+  static constexpr bool kRolled = kK_ * kCB_ >= 14;
   static_assert(kK_ % 2 == 1 && kK_ >= 3 && kK_ <= 7 && kCB_ >= 1 && kCB_ <= 2, "tower geometry");
 };
 typedef Tower<kKW, 1> DefaultTower;
@@ -870,6 +873,117 @@ __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const La
     }
 }
 
+// The same layer as a loop over the taps (Tower::kRolled).  One tap = 4 kCB operand groups;
+// the weight ring is four groups deep (three requested ahead) so that its slot indices repeat
+// with the tap, operands are double-buffered as above.  The operand rows of a tap are
+// recomputed inside the loop (a run-time index into a register array would be a scratch
+// array); the last tap's read-ahead re-reads its own first groups instead of running past
+// the layer.
+template <class TW>
+__device__ __forceinline__ int tap_row_one(const Lane& ln, int trow, int n, bool pow2, int k) {
+  constexpr int kLeft = TW::kK / 2;
+  if (pow2) {
+    const int mask = n - 1;
+    return ((trow + k - kLeft) & mask) | (trow & ~mask);
+  }
+  const int base = row_sample(trow, ln.inv_n) * n;
+  int q = trow - base + k - kLeft;
+  q = q < 0 ? q + n : q;
+  q = q >= n ? q - n : q;
+  return trow < ln.rows_used ? base + q : trow;
+}
+
+template <class TW, int kWR>
+__device__ __forceinline__ void hidden_layer_rolled(const DevParams& p, const Lane& ln,
+                                                    int hidden_index, const float* in,
+                                                    float* out, int n, bool pow2, int act) {
+  constexpr int kT = kWR / 32, kCB = TW::kCB, kGT = 4 * kCB, kRing = 4, kAhead = kRing - 1;
+  static_assert(kGT % kRing == 0, "ring slots repeat with the tap");
+  const int j = ln.lane & 31, half = ln.lane >> 5;
+  const float* __restrict__ layer = p.w_hidden + (size_t)hidden_index * stream_layer_floats<TW>();
+  const float4* __restrict__ wq = reinterpret_cast<const float4*>(layer) + opaque(ln.lane);
+  const float* __restrict__ wbias = layer + TW::kHidGroups * kCB * 64 * 4 + opaque(ln.lane);
+  const char* inb = reinterpret_cast<const char*>(in);
+  f32x16 acc[kCB][kT];
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[h][t][r] = 0.0f;
+  float wb[kCB];
+#pragma unroll
+  for (int h = 0; h < kCB; ++h) wb[h] = wbias[h * 64];
+  float4 wbuf[kRing][kCB], bbuf[2][kT];
+#pragma unroll
+  for (int g = 0; g < kAhead; ++g)
+#pragma unroll
+    for (int h = 0; h < kCB; ++h) wbuf[g][h] = wq[(g * kCB + h) * 64];
+  int trow[kT], ro[kT];
+#pragma unroll
+  for (int t = 0; t < kT; ++t) {
+    trow[t] = ln.wave * kWR + t * 32 + j;
+    ro[t] = (int)__umul24((unsigned)tap_row_one<TW>(ln, trow[t], n, pow2, 0), (unsigned)(TW::kHS * 4)) + 64 * half;
+    bbuf[0][t] = *reinterpret_cast<const float4*>(inb + ro[t]);
+  }
+#pragma unroll 1
+  for (int tap = 0; tap < TW::kK; ++tap) {
+    const bool more = tap + 1 < TW::kK;   // wave-uniform
+    int ro_next[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t)
+      ro_next[t] = (int)__umul24((unsigned)tap_row_one<TW>(ln, trow[t], n, pow2, more ? tap + 1 : tap),
+                                 (unsigned)(TW::kHS * 4)) + 64 * half;
+    const float4* __restrict__ wt = wq + (size_t)tap * (kGT * kCB * 64);
+    const float4* __restrict__ wt_ahead = more ? wt : wt - kGT * kCB * 64;   // (groups past the tap)
+#pragma unroll
+    for (int gi = 0; gi < kGT; ++gi) {
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+        wbuf[(gi + kAhead) % kRing][h] =
+            (gi + kAhead < kGT ? wt : wt_ahead)[((gi + kAhead) * kCB + h) * 64];
+#pragma unroll
+      for (int t = 0; t < kT; ++t)
+        bbuf[(gi + 1) & 1][t] = *reinterpret_cast<const float4*>(
+            inb + (gi + 1 < kGT ? ro[t] + 128 * (((gi + 1) / 4) % kCB) + 16 * ((gi + 1) % 4) : ro_next[t]));
+      const float4* wg = wbuf[gi % kRing];
+      const float4* bg = bbuf[gi & 1];
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].x, bg[t].x, acc[h][t]);
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].y, bg[t].y, acc[h][t]);
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].z, bg[t].z, acc[h][t]);
+#pragma unroll
+      for (int h = 0; h < kCB; ++h)
+#pragma unroll
+        for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wg[h].w, bg[t].w, acc[h][t]);
+      __builtin_amdgcn_sched_group_barrier(0x020, kCB, 0);           // VMEM reads
+      __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);            // DS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * kCB * kT, 0);  // MFMAs
+    }
+#pragma unroll
+    for (int t = 0; t < kT; ++t) ro[t] = ro_next[t];
+  }
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) acc[h][t] = DDD_MFMA32(wb[h], 1.0f, acc[h][t]);   // bias row
+#pragma unroll
+  for (int h = 0; h < kCB; ++h)
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+      activate16(acc[h][t], act);
+      store_tile32_at<TW::kHS>(out, ln.wave * kWR + t * 32 + j, h, half, acc[h][t]);
+    }
+}
+
 // Output layer (32 -> C_out <= 16, linear) on v_mfma_f32_4x4x1_16b_f32.  A
 // 16x16x4 formulation pads the 11-14 live output channels to 16 and leaves the
 // result in a (position, channel-quad) layout that has to travel through LDS to
@@ -1215,7 +1329,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     for (int l = 1; l < nL - 1; ++l) {
       if constexpr (!TW::kDefault) {
         group_barrier<kRows, kWR>();
-        if (l == 1 && res.hw_valid)
+        if constexpr (TW::kRolled)
+          hidden_layer_rolled<TW, kWR>(p, ln, l - 1, in, out, p.N, pow2, act);
+        else if (l == 1 && res.hw_valid)
           hidden_layer_stream<TW, kWR, resident_groups<TW>()>(p, ln, 0, in, out, hid_rows, act,
                                                               res.hw, res.hwb);
         else
@@ -1736,7 +1852,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
 #pragma unroll
   for (int s = 0; s < kInSteps; ++s) res.w_in[s] = 0.0f;
-  if constexpr (!TW::kDefault && kKeepTower) {
+  if constexpr (!TW::kDefault && !TW::kRolled && kKeepTower) {
     // streamed towers: the leading groups of hidden layer 0 (resident_groups)
     constexpr int kRes = resident_groups<TW>();
     static_assert(kRes * TW::kCB <= kResidentQuads, "Resident::hw");

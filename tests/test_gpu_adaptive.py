@@ -341,10 +341,11 @@ def test_start_time_is_not_zero_and_single_sample_batches():
 
 
 @pytest.mark.parametrize('overrides', [dict(kernel_size=7), dict(filter_size=64),
-                                       dict(kernel_size=3)])
+                                       dict(kernel_size=3),
+                                       dict(kernel_size=7, filter_size=64)])
 def test_other_towers_adaptive(overrides):
   """The adaptive integrator on the towers with streamed weights (7 taps, 64
-  filters, 3 taps): per-sample nfev equal to the reference run, both geometries."""
+  filters, both, 3 taps): per-sample nfev equal to the reference run, both geometries."""
   for num_points in (64, 96):
     model = make_model('burgers', True, num_points=num_points, resample_factor=4, **overrides)
     assert model.kernel_name.startswith('mfma_f32')

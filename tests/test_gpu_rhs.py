@@ -258,11 +258,15 @@ def test_smaller_towers_embedded_in_the_mfma_layers(overrides):
     dict(kernel_size=7, model_target='time_derivative'),
     dict(filter_size=64, model_target='space_derivatives'),
     dict(kernel_size=3, num_layers=2),                         # the 3-tap tower, no hidden layer
+    dict(kernel_size=7, filter_size=64),                       # hidden layers as a loop over the taps
+    dict(kernel_size=6, filter_size=48, num_layers=4, nonlinearity='tanh'),   # embedded in 7 x 64
+    dict(kernel_size=3, filter_size=64),                       # embedded in 5 x 64
+    dict(kernel_size=7, filter_size=64, model_target='time_derivative'),
 ])
 def test_other_towers_on_mfma(overrides):
   """training.py:134-136 leaves kernel_size and filter_size free, model.py:455-458
-  builds whatever they say: 7 taps, 64 filters and 3 taps have MFMA towers of
-  their own (rhs_mfma.h Tower<7, 1>, <5, 2>, <3, 1>: weights streamed from L2),
+  builds whatever they say: 7 taps, 64 filters, both, and 3 taps have MFMA towers of
+  their own (rhs_mfma.h Tower<7, 1>, <5, 2>, <7, 2>, <3, 1>: weights streamed from L2),
   nets in between are embedded with zero weights.  One-wave (N = 64) and
   four-wave (N = 96) groups, all views and 10 midpoint steps against the oracle
   evaluating the TRUE net; the generic kernel agrees; launch modes agree bit
@@ -335,13 +339,12 @@ def test_one_layer_nets_on_the_valu_route(overrides):
 @pytest.mark.parametrize('overrides', [
     dict(num_layers=1, polynomial_accuracy_order=0, ensure_unbiased_coefficients=True),
     dict(filter_size=96), dict(kernel_size=9),
-    dict(kernel_size=7, filter_size=64),
     dict(coefficient_grid_min_size=13), dict(num_layers=0),
 ])
 def test_generic_only_variants(overrides):
-  """Configurations the MFMA path does not cover (more than 64 filters or 7 taps, 7
-  taps together with 64 filters, one-layer nets with mean-subtracted coefficients,
-  stencils wider than 12) run on the generic kernel (never on the CPU)."""
+  """Configurations the MFMA path does not cover (more than 64 filters or 7 taps,
+  one-layer nets with mean-subtracted coefficients, stencils wider than 12) run on
+  the generic kernel (never on the CPU)."""
   conservative = not overrides.get('ensure_unbiased_coefficients', False)
   model = make_model('burgers', conservative, num_points=64, **overrides)
   if overrides.get('num_layers', 3) != 0:
