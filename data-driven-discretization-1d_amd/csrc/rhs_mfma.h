@@ -859,6 +859,13 @@ __device__ __forceinline__ void hidden_layer_stream(const DevParams& p, const La
     }
 #pragma unroll
   for (int t = 0; t < kT; ++t) st.bbuf[0][t] = stream_operand<TW, kT, 0>(st, t);
+  // The requests above stay above: without this fence they share the scheduling region of
+  // the groups below, whose "kCB VMEM reads, then the MFMAs" slots are filled in program
+  // order -- the FIRST slot took the first request of the prologue, every later one the
+  // request meant for kStreamAhead groups earlier, and each group's weights arrived right
+  // before its own MFMAs: `global_load_dwordx4 ; s_waitcnt vmcnt(0) ; v_mfma` in every group
+  // of every streamed layer of rounds 3-4 (found in round 5's ISA census).
+  __builtin_amdgcn_sched_barrier(0);
   stream_groups<TW, kT, kRes>(st, hw, std::make_integer_sequence<int, kG>{});
 #pragma unroll
   for (int h = 0; h < kCB; ++h)
