@@ -84,8 +84,8 @@ CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burger
                 'rk_substep_external', 'stream_fixed', 'stream_fixed_per_step',
                 'differentiator_b1', 'adaptive_rk23',
                 'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024',
-                'tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096', 'burgers_b256',
-                'one_layer_b4096')
+                'tower_k7_b4096', 'tower_f64_b4096', 'tower_k7f64_b4096', 'tower_k3_b4096',
+                'wide_ks_g9_b4096', 'burgers_b256', 'one_layer_b4096')
 
 
 def parse_args(argv=None):
@@ -896,8 +896,16 @@ def extra_configs(args, lib, world):
             262144, unique=4096,
             **dict(base, equation='kdv', baseline_stencils=True, launch_mode='per_step',
                    steps=200))
-      elif name in ('tower_k7_b4096', 'tower_f64_b4096', 'tower_k3_b4096'):
+      elif name == 'wide_ks_g9_b4096':
+        hp = {'coefficient_grid_min_size': 9}
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'KS N=64 with 9-point stencils (coefficient_grid_min_size = 9, '
+            'training_test.py:56): the wide flavour of the run-time MFMA kernels, output layer '
+            'folded to the 27 coefficients; fractions in TRUE-net FLOPs', 4096,
+            **dict(base, equation='ks', hparams=json.dumps(hp), steps=200))
+      elif name in ('tower_k7_b4096', 'tower_f64_b4096', 'tower_k7f64_b4096', 'tower_k3_b4096'):
         hp = {'tower_k7_b4096': {'kernel_size': 7}, 'tower_f64_b4096': {'filter_size': 64},
+              'tower_k7f64_b4096': {'kernel_size': 7, 'filter_size': 64},
               'tower_k3_b4096': {'kernel_size': 3}}[name]
         key, val = _fixed_step_config(
             args, lib, world, name, 'the headline workload with hyper-parameters {} '
