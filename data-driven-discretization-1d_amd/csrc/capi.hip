@@ -695,7 +695,7 @@ void decide_mfma(ddd_model* m) {
   if (dp.G > dp.N) no("stencil wider than the grid");
   if (dp.fixed && dp.weno) no("WENO reconstruction");
   // The wide flavour of the run-time-parameterised kernels (stencils up to 12
-  // points, up to 24 output channels, projection in the epilogue) carries what
+  // points, up to 24 net output channels, projection folded into the output layer) carries what
   // the default flavour (8 points, 16 channels) cannot: coefficient_grid_min_size
   // = 9 and polynomial_accuracy_order = 0 with three derivatives
   // (training_test.py:56-57).
