@@ -114,6 +114,9 @@ __host__ __device__ constexpr int fin4_regs_t(int groups) { return (TW::kFinK * 
 // per SIMD (single activation buffer: 11.9 KB of LDS, 168 VGPRs, two resident weight groups)
 // measured below two wavefronts with the whole hidden layer resident (241 VGPRs): 62.9 vs
 // 64.4 % at 4 096 samples, 39.7 vs 50.5 % with one launch per substep.
+#ifndef DDD_PRIO_PHASES
+#define DDD_PRIO_PHASES 0   // measured neutral (profiles/r5_ablation.txt): off
+#endif
 #ifndef DDD_K3_WAVES
 #define DDD_K3_WAVES 2
 #endif
@@ -1323,6 +1326,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   for (int c = 0; c < kCh; ++c) net[c] = 0.0f;
   if (!fixed) {
     DDD_STAMP(1);
+    // A/B (DDD_PRIO_PHASES): the matrix phases of an evaluation at raised issue priority, the
+    // VALU phases (epilogue, forcing, Runge-Kutta update) at the lowest
+    if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(3);
     if constexpr (!TW::kDefault) {
       input_layer_big<TW, kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, hid_rows, act);
     } else if (!(ablate & 16)) {
@@ -1520,6 +1526,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       }
       }   // !kSplit
       DDD_STAMP(3);
+      if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(0);
     }
   } else {
     if (forced && fast_forcing && prepare_next && !(ablate & 1))
