@@ -1112,6 +1112,7 @@ struct Resident {
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
   int frc_run;              // its run of modes: (float offset into Shared::pm) | count << 16
                             // | (index of the sum in Shared::fk) << 24; 0: lane carries none
+  int frc_pairs;            // lanes of forcing phase 1: (samples | batches) x P (wave-uniform)
   int frc_slot;             // index of this lane's sum in Shared::fk (fixed by the lane, not by
                             // the sample), -1: the lane carries no (sample, k, sin|cos) slot
 #ifdef DDD_PROBES
@@ -1130,10 +1131,12 @@ struct Resident {
 // at the start of the evaluation that uses it.  Inside an evaluation the two
 // phases sit at the input->hidden and hidden->output layer boundaries, where
 // the wavefront otherwise only waits for its activations to land in LDS.
+// (t: per lane -- forcing batches give every batch of lanes its own evaluation time;
+// res.frc_pairs: (samples or batches of the group) x P)
 template <int kRows, int kWR, bool kWide, class TW>
 __device__ __forceinline__ void forcing_phase1(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                                const Resident& res, float t, int tid) {
-  if (tid < (kRows / p.N) * p.P) {
+  if (tid < res.frc_pairs) {
     float sn, cs;
     sincos_branchless(res.frc_omega * t + res.frc_phi, &sn, &cs);
     sm.pm[tid] = make_float2(res.frc_a * sn, res.frc_a * cs);
@@ -1797,7 +1800,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
 
 template <int kRows, int kWR, bool kWide, class TW>
 __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
-                                              int block, int batch, Resident& res, bool fast);
+                                              int block, int batch, Resident& res, bool fast,
+                                              int nb = 1);
 
 // The forcing of this launch can take the harmonic-sum path (else: per-point sinf).
 template <int kRows, int kWR>
@@ -1805,6 +1809,32 @@ __device__ __forceinline__ bool forcing_is_fast(const DevParams& p) {
   const int spg = kRows / p.N;
   return p.forced && spg * p.P <= Shared<kRows, kWR>::kPmMax && p.n_k <= 6 &&
          spg * kTrigMax <= Shared<kRows, kWR>::kFkMax && p.P < 256;
+}
+
+// Forcing BATCHES (persistent one-wave integrators, one sample per wavefront): phases 1 and 2
+// of the harmonic sums occupy P = 20 and 2 n_k <= 12 lanes of 64, and every VALU instruction
+// costs the matrix pipe its issue time whatever its lane mask.  With the evaluation times of a
+// fixed-step scheme known in advance, lanes [b P, (b + 1) P) take the time of the (b + 1)-th
+// next evaluation: one pass of phases 1 + 2 in every `nb`-th evaluation serves the next nb
+// (43 instructions per pass: ~14 per evaluation instead of 43).  Every element is computed
+// by the same instructions from the same operands as before -- the same bits as the
+// one-launch-per-substep kernels.  Layout: batch b is "sample slot" b of the staging
+// buffers (Shared::pm set b at entry b P, Shared::fk set b at entry b kTrigMax), exactly
+// where the samples of a multi-sample group sit; phase 3 reads set e mod nb.
+// MEASURED NEUTRAL (profiles/r5_ablation.txt: 82.5 % with and without; 61 GPU tests incl. the
+// bit-for-bit launch-mode comparisons passed with it): phases 1 and 2 already sit in the LDS
+// waits at the layer boundaries, their instructions were not what the matrix pipe waited
+// for.  Off by default; -DDDD_FORCING_BATCH=1 builds it.
+#ifndef DDD_FORCING_BATCH
+#define DDD_FORCING_BATCH 0
+#endif
+constexpr int kForcingBatchMax = 3;
+template <int kRows, int kWR>
+__device__ __forceinline__ int forcing_batches(const DevParams& p) {
+  if (!DDD_FORCING_BATCH || kRows != 64 || kWR != 64 || !forcing_is_fast<kRows, kWR>(p)) return 1;
+  if (2 * p.N <= kRows) return 1;   // more than one sample per wavefront: no spare lanes
+  const int nb = p.P > 0 ? 64 / p.P : 1;
+  return nb > kForcingBatchMax ? kForcingBatchMax : (nb < 1 ? 1 : nb);
 }
 
 // The per-lane loop invariants of the kernels that keep them resident
@@ -1846,7 +1876,7 @@ __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln,
 // Per-launch setup, part 1: resident registers and the tables in LDS.
 template <int kRows, int kWR, bool kHoist, bool kKeepTower = true, bool kWide, class TW>
 __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
-                                              const Lane& ln, Resident& res) {
+                                              const Lane& ln, Resident& res, int nb = 1) {
   constexpr int kThreads = kRows / kWR * 64;
   const int tid = group_tid<kRows, kWR>();
   constexpr int kGW = flavour_stencil(kWide);
@@ -1916,10 +1946,12 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
   // ---- index math (no memory) ----
   {
-    const int spg = kRows / p.N;
+    // (forcing batches, nb > 1: one sample per wavefront, batch b in "sample slot" b)
+    const int spg = nb > 1 ? nb : kRows / p.N;
     const int sl = row_sample(tid >> 1, p.inv_nk);   // exact
     res.frc_slot = (fast && tid < spg * p.n_k * 2)
                        ? sl * kTrigMax + 2 * ((tid >> 1) - sl * p.n_k) + (tid & 1) : -1;
+    res.frc_pairs = spg * p.P;
   }
   res.fk_off = opaque(ln.sl * kTrigMax * 4);   // (fixed-stencil models with forcing read it too)
   res.st_off = 0;
@@ -1953,9 +1985,10 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
 // Per-launch setup of the persistent integrators and the one-group substep kernel.
 template <int kRows, int kWR, bool kHoist, bool kKeepTower = true, bool kWide, class TW>
 __device__ __forceinline__ bool launch_setup(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
-                                             const Lane& ln, int batch, Resident& res) {
-  const bool fast = setup_weights<kRows, kWR, kHoist, kKeepTower>(p, sm, ln, res);
-  setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast);
+                                             const Lane& ln, int batch, Resident& res,
+                                             int nb = 1) {
+  const bool fast = setup_weights<kRows, kWR, kHoist, kKeepTower>(p, sm, ln, res, nb);
+  setup_samples<kRows, kWR>(p, sm, (int)blockIdx.x, batch, res, fast, nb);
   return fast;
 }
 
@@ -1974,9 +2007,12 @@ struct SampleSetup {
 
 template <int kRows, int kWR>
 __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int block, int batch,
-                                                     bool fast) {
+                                                     bool fast, int nb = 1) {
   const int tid = group_tid<kRows, kWR>();
   const int spg = kRows / p.N;
+  // forcing batches (nb > 1, spg == 1): "sample slot" b of the staging buffers holds batch b
+  // of the group's ONE sample -- the same index math with nb slots, all reading sample 0
+  const int slots = nb > 1 ? nb : spg;
   SampleSetup s{0.0f, 0.0f, 0.0f, 0, 0, 0};
   if (fast) {   // wave-uniform
     // Both loads are UNCONDITIONAL (lanes without a pair / slot, and samples past
@@ -1986,16 +2022,16 @@ __device__ __forceinline__ SampleSetup fetch_samples(const DevParams& p, int blo
     // its weights is what made the start of a launch cost more than an
     // evaluation (profiles/tools/substep_wave_trace.py).
     const int fsl = row_sample(tid, p.inv_P);   // tid / P, exact
-    const long sample = (long)block * spg + fsl;
-    const bool has_pair = tid < spg * p.P && sample < batch;
+    const long sample = (long)block * spg + (nb > 1 ? 0 : fsl);
+    const bool has_pair = tid < slots * p.P && sample < batch;
     const float4* __restrict__ row = p.frc + (has_pair ? sample * p.P + (tid - fsl * p.P) : 0);
     s.a = row->x; s.omega = row->y; s.phi = row->z;
     // this lane's run of modes [m0, m1): runs[sample][kk] = first (sorted) mode of
     // the sample whose k index is >= kk, precomputed by ddd_set_forcing
     const int sl = row_sample(tid >> 1, p.inv_nk);   // exact
     const int kk = (tid >> 1) - sl * p.n_k;
-    const long sample2 = (long)block * spg + sl;
-    s.has_slot = tid < spg * p.n_k * 2 && sample2 < batch;
+    const long sample2 = (long)block * spg + (nb > 1 ? 0 : sl);
+    s.has_slot = tid < slots * p.n_k * 2 && sample2 < batch;
     const unsigned char* __restrict__ rr = p.runs + (s.has_slot ? sample2 * 8 + kk : 0);
     s.runs_raw = (int)rr[0] | ((int)rr[1] << 8);
     s.run_base = (2 * (sl * p.P) + (tid & 1)) | ((sl * kTrigMax + 2 * kk + (tid & 1)) << 24);
@@ -2025,8 +2061,8 @@ __device__ __forceinline__ void apply_samples(Shared<kRows, kWR, kWide, TW>& sm,
 template <int kRows, int kWR, bool kWide, class TW>
 __device__ __forceinline__ void setup_samples(const DevParams& p, Shared<kRows, kWR, kWide, TW>& sm,
                                               int block, int batch, Resident& res,
-                                              bool fast) {
-  apply_samples<kRows, kWR>(sm, res, fetch_samples<kRows, kWR>(p, block, batch, fast));
+                                              bool fast, int nb) {
+  apply_samples<kRows, kWR>(sm, res, fetch_samples<kRows, kWR>(p, block, batch, fast, nb));
 }
 
 // ---------------------------------------------------------------------------
@@ -2248,7 +2284,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   __shared__ Shared<kRows, kWR, kWide, TW> sm;
   const Lane ln = make_lane<kRows, kWR>(p, a.batch, (int)threadIdx.x, (int)blockIdx.x);
   Resident res;
-  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res);
+  // forcing batches (per-equation kernels: registers to spare; see forcing_batches)
+  const int nb = (kEq >= 0 && kHoist) ? forcing_batches<kRows, kWR>(p) : 1;
+  const bool fast_frc = launch_setup<kRows, kWR, kHoist>(p, sm, ln, a.batch, res, nb);
   // (Two wavefronts share each SIMD and run the same phases.  Static priorities
   // by hardware wave slot and start staggering were measured and change nothing
   // (profiles/r2_ablation.txt); the switches survive in the probe build only.)
@@ -2283,9 +2321,23 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
   int until_save = a.save_every;
   size_t snap = 0;
   int evals = 0;
-  if (fast_frc && !(ablate & 1))
-    res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, (float)(a.t0 + a.tab.c[0] * a.dt),
-                                                  (int)threadIdx.x);
+  // time of the evaluation `ahead` evaluations after stage s of step `step` (ahead >= 0),
+  // in the arithmetic of the loop below; this lane's batch of forcing phase 1
+  const int frc_b = nb > 1 ? row_sample((int)threadIdx.x, p.inv_P) : 0;
+  // (the stage time by an indexed read: one pass in nb evaluations)
+  const auto time_ahead = [&](int step, int s, int ahead) {
+    for (int i = 0; i < ahead; ++i) { if (++s == a.tab.stages) { s = 0; ++step; } }
+    return (float)((a.t0 + (double)step * a.dt) + a.sc.ct[s]);
+  };
+  if (fast_frc && !(ablate & 1)) {
+    float t_lane = (float)(a.t0 + a.tab.c[0] * a.dt);
+    if (nb > 1) {   // batch b: evaluation b of the launch
+      const float t1 = time_ahead(0, 0, 1), t2 = time_ahead(0, 0, 2);
+      t_lane = frc_b == 0 ? t_lane : frc_b == 1 ? t1 : t2;
+    }
+    res.fk_next = forcing_sums<kRows, kWR>(p, sm, res, t_lane, (int)threadIdx.x);
+  }
+  int frc_phase = 0;   // evaluation index mod nb: the set of Shared::fk this evaluation reads
   // (the per-stage products a[s] h, b[s] h, c[s] dt: StageConsts, formed on the host in this
   // arithmetic -- (ST)a[s] * (ST)dt etc. -- and picked by scalar selects)
   (void)h;
@@ -2308,9 +2360,22 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
       // next step): its forcing sums are prepared inside this evaluation
       const bool last = s + 1 == a.tab.stages;
       const double tn = (last ? t_after : t) + ct.at(last ? 0 : s + 1);
+      float tn_lane = (float)tn;
+      bool prepare = true;
+      if (nb > 1) {
+        // batches: this evaluation reads set frc_phase; the last one of a batch prepares
+        // the next nb evaluations (lanes of batch b: the (b + 1)-th next evaluation)
+        res.fk_off = frc_phase * (kTrigMax * 4);
+        prepare = frc_phase == nb - 1;
+        if (prepare) {
+          const float t2 = time_ahead(step, s, 2), t3 = time_ahead(step, s, 3);
+          tn_lane = frc_b == 0 ? tn_lane : frc_b == 1 ? t2 : t3;
+        }
+        frc_phase = prepare ? 0 : frc_phase + 1;
+      }
       const float f = eval_rhs<kRows, kWR, kHoist, kEq, kTrace>(
-          p, sm, a.batch, (float)us, (float)(t + ct.at(s)), (float)tn, res, fast_frc,
-          nullptr, nullptr, true, -1, ablate, tr);
+          p, sm, a.batch, (float)us, (float)(t + ct.at(s)), tn_lane, res, fast_frc,
+          nullptr, nullptr, prepare, -1, ablate, tr);
       if ((a.sc.b_nonzero >> s) & 1) ynew = ynew + bh.at(s) * (ST)f;
       kprev = f;
     }
