@@ -429,6 +429,8 @@ def emulate_big_tower(un_rows, n, kernels, biases, taps, blocks, groups):
     (64, 3, 9, 7, 32, 7, 1), (64, 3, 12, 5, 64, 5, 2), (32, 3, 8, 3, 32, 3, 1),
     (96, 4, 11, 6, 20, 7, 1),      # embedded: 6 taps x 20 filters in 7 x 32
     (128, 2, 9, 4, 40, 5, 2),      # embedded: 4 taps x 40 filters in 5 x 64, no hidden layer
+    (64, 3, 10, 7, 64, 7, 2),      # 7 taps x 64 filters (the kernel rolls its hidden layers over the taps;
+    (64, 3, 8, 6, 48, 7, 2),       #   same packed layout), and 6 x 48 embedded in it
 ])
 def test_emulated_streamed_towers_match_oracle(n, num_layers, c_out, k_true, f_true, taps, blocks):
   rs = np.random.RandomState(n + taps + blocks)
@@ -449,3 +451,65 @@ def test_emulated_streamed_towers_match_oracle(n, num_layers, c_out, k_true, f_t
   got = net[:samples * n, :c_out].reshape(samples, n, c_out)
   np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
   assert np.all(net[:samples * n, c_out:] == 0)
+
+
+def wide_slot(g):
+  """rhs_mfma.h: wide_slot -- channels per derivative of the wide flavour's folded output layer."""
+  return 8 if g <= 8 else g
+
+
+def fold_wide_output_layer(w_nat, b_nat, nullspaces, acc_biases, g):
+  """capi.hip::pack_mfma_weights, wide flavour (always folded): output channel
+  wide_slot(G) d + g' of the folded layer = sum_j W[:, start_d + j] * nullspace_d[j, g']
+  (float64 accumulation, rounded once), bias row = accuracy bias + projected conv bias."""
+  kc, slot = w_nat.shape[0], wide_slot(g)
+  cols = 36
+  wf, bf = np.zeros((kc, cols), np.float32), np.zeros(cols, np.float32)
+  start = 0
+  for d, (ns, ab) in enumerate(zip(nullspaces, acc_biases)):
+    if ns is None:   # polynomial_accuracy_order 0: channel G d + g' IS the coefficient
+      wf[:, slot * d:slot * d + g] = w_nat[:, g * d:g * d + g]
+      bf[slot * d:slot * d + g] = b_nat[g * d:g * d + g]
+      continue
+    stop = start + ns.shape[0]
+    wf[:, slot * d:slot * d + g] = (w_nat[:, start:stop].astype(np.float64) @ ns.astype(np.float64)).astype(np.float32)
+    bf[slot * d:slot * d + g] = (ab.astype(np.float64) + b_nat[start:stop].astype(np.float64) @ ns.astype(np.float64)).astype(np.float32)
+    start = stop
+  return wf, bf
+
+
+@pytest.mark.parametrize('g,free,direct', [(9, (7, 6, 4), False), (12, (10, 9), False),
+                                          (10, (8, 7, 5), False), (7, None, True), (9, None, True)])
+def test_wide_fold_equals_projection(g, free, direct):
+  """The wide kernels have no projection code: their output layer is folded on the host.
+  The folded layer applied to the last hidden activations must give the coefficients
+  bias + net @ nullspace (polynomials.py:275-277) -- or the net's own channels
+  (model.py:460-475) -- in slots of wide_slot(G) per derivative, zeros elsewhere."""
+  rs = np.random.RandomState(g)
+  derivs = 3 if direct or len(free) == 3 else 2
+  c_out = derivs * g if direct else sum(free)
+  kc = 160
+  w_nat = (rs.randn(kc, c_out) * 0.2).astype(np.float32)
+  b_nat = (rs.randn(c_out) * 0.1).astype(np.float32)
+  hidden = np.maximum(rs.randn(50, kc), 0).astype(np.float32)     # relu activations, [rows][tap, cin]
+  if direct:
+    nullspaces, acc_biases = [None] * derivs, [None] * derivs
+  else:
+    nullspaces = [rs.randn(f, g).astype(np.float32) for f in free]
+    acc_biases = [rs.randn(g).astype(np.float32) for _ in free]
+  wf, bf = fold_wide_output_layer(w_nat, b_nat, nullspaces, acc_biases, g)
+  got = hidden.astype(np.float64) @ wf.astype(np.float64) + bf
+  net = hidden.astype(np.float64) @ w_nat.astype(np.float64) + b_nat
+  slot, start = wide_slot(g), 0
+  used = np.zeros(36, bool)
+  for d in range(derivs):
+    if direct:
+      want = net[:, g * d:g * d + g]
+    else:
+      stop = start + free[d]
+      want = acc_biases[d] + net[:, start:stop] @ nullspaces[d].astype(np.float64)
+      start = stop
+    np.testing.assert_allclose(got[:, slot * d:slot * d + g], want, rtol=2e-5, atol=2e-5)
+    used[slot * d:slot * d + g] = True
+  assert derivs * slot - (slot - g) <= 36            # the channels the kernel carries
+  assert np.all(wf[:, ~used] == 0) and np.all(bf[~used] == 0)
