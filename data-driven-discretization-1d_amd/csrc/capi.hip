@@ -16,6 +16,7 @@
 #include "../../include/ddd1d.h"
 #include "dev_params.h"
 #include "launch.h"
+#include "launch_weno.h"
 #include "ops.h"
 #ifdef DDD_PROBES
 #include "probe_kernels.h"
@@ -25,6 +26,7 @@
 #include "rhs_mfma.h"
 #include "rhs_spectral.h"
 #include "rhs_stream.h"
+#include "rhs_weno.h"   // (host side only: weno::supports; the kernels are weno_unit.hip)
 
 namespace {
 
@@ -42,6 +44,7 @@ struct DebugOptions {
   int no_spec = 0;       // run-time-parameterised kernels instead of the per-equation ones
   int no_stream = 0;     // per-sample kernels instead of the streaming fixed-stencil kernel
   int no_lean = 0;       // the MFMA-path kernels (tower skipped) instead of rhs_lean.h
+  int no_weno = 0;       // the generic kernel instead of rhs_weno.h
   int no_fft = 0;        // spectral models: the O(N^2) circulant form at every N
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
@@ -859,6 +862,14 @@ bool use_stream_kernel(const ddd_model* m, const ddd::SubstepArgs& a) {
          aligned16(a.acc_in) && aligned16(a.acc_out);
 }
 
+// WENO5 + Godunov-flux models (integrate.WENODifferentiator, the exact Burgers solver) on
+// the one-wavefront-per-sample kernels of rhs_weno.h; an explicit ddd_set_kernel(GENERIC)
+// keeps the generic kernel (A/B, and the grids rhs_weno.h does not carry).
+bool use_weno_kernel(const ddd_model* m) {
+  return m->kernel == DDD_KERNEL_GENERIC && !m->explicit_kernel && !g_debug.no_weno &&
+         ddd::weno::supports(m->dp);
+}
+
 // sample0: index of a.y_in's first sample in the model's per-sample tables (a
 // half-ensemble launch); grid_share: this launch may occupy 1 / grid_share of
 // the machine-sized grid (it runs next to grid_share - 1 others).
@@ -925,6 +936,13 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
         }
     }
 #undef DDD_SUBSTEP_CASE
+  } else if (use_weno_kernel(m) && a.coeffs_out == nullptr) {
+    ddd::DevParams dp = m->dp;
+    if (sample0 != 0 && dp.forced) {   // per-sample forcing rows of this slab
+      dp.frc += (size_t)sample0 * dp.P;
+      dp.runs += (size_t)sample0 * 8;
+    }
+    ddd::launch::weno_substep(dp, a, stream);
   } else {
     int rc = check_generic_lds(m, 0);
     if (rc) return rc;
@@ -1057,6 +1075,8 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
     else if (geo.rows == 64) launch_mfma_integrate<64, 32, ST>(m, a, stream);
     else launch_mfma_integrate<256, 64, ST>(m, a, stream);
+  } else if (use_weno_kernel(m)) {
+    ddd::launch::weno_integrate(std::is_same<ST, double>::value, m->dp, a, stream);
   } else {
     int rc = check_generic_lds(m, (int)sizeof(ST));
     if (rc) return rc;
@@ -2064,9 +2084,14 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
 #undef DDD_SPECTRAL_ADAPTIVE
     return enqueued();
   }
+  if (use_weno_kernel(m)) {
+    // the WENO5 + Godunov-flux exact solver: one wavefront and one controller per sample
+    ddd::launch::weno_adaptive(m->dp, a, stream);
+    return enqueued();
+  }
   if (m->kernel != DDD_KERNEL_MFMA) {
-    // generic right-hand side (WENO5 exact solver, nets the MFMA path does not carry):
-    // one workgroup and one controller per sample
+    // generic right-hand side (nets the MFMA path does not carry, WENO on grids that are
+    // not 64 x {1, 2, 4, 8} points): one workgroup and one controller per sample
     const size_t lds = ddd::generic::adaptive_lds_bytes(m->dp);
     if (lds > 160 * 1024)
       return fail(DDD_ERR_UNSUPPORTED,
@@ -2269,6 +2294,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m->spectral) return "spectral_f64";
   if (m->last_launch_streamed) return "stream_fixed";
   if (m->last_launch_lean) return "valu_f32_lean";
+  if (use_weno_kernel(m)) return "valu_f32_weno";
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
@@ -2289,6 +2315,7 @@ DDD_API int ddd_debug_set_option(const char* name, long long value) {
   else if (key == "no_spec") g_debug.no_spec = (int)value;
   else if (key == "no_stream") g_debug.no_stream = (int)value;
   else if (key == "no_lean") g_debug.no_lean = (int)value;
+  else if (key == "no_weno") g_debug.no_weno = (int)value;
   else if (key == "no_fft") g_debug.no_fft = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;

@@ -19,11 +19,19 @@ def pad_periodic(inputs, padding: int, center: bool = False):
 def _dilate(kernel, dilation_rate: int):
   """[K, cin, cout] -> [(K - 1) d + 1, cin, cout] with zero taps between the K real ones:
   a dilated VALID convolution over the periodically padded input is the plain one with
-  this kernel (padding (K - 1) d either way, layers.py:128-129)."""
-  import numpy as np
-  kernel = kernel.cpu().numpy() if hasattr(kernel, 'cpu') else np.asarray(kernel)
+  this kernel (padding (K - 1) d either way, layers.py:128-129).  The default
+  (dilation 1) hands the caller's tensor through untouched -- no host round trip --;
+  the zero-stuffed kernel is built on the tensor's own device."""
   if dilation_rate == 1:
     return kernel
+  if hasattr(kernel, 'new_zeros'):   # torch tensor, any device
+    kernel = kernel.detach()
+    k = kernel.shape[0]
+    out = kernel.new_zeros(((k - 1) * dilation_rate + 1,) + tuple(kernel.shape[1:]))
+    out[::dilation_rate] = kernel
+    return out
+  import numpy as np
+  kernel = np.asarray(kernel)
   k = kernel.shape[0]
   out = np.zeros(((k - 1) * dilation_rate + 1,) + kernel.shape[1:], kernel.dtype)
   out[::dilation_rate] = kernel
