@@ -85,7 +85,11 @@ CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burger
                 'differentiator_b1', 'adaptive_rk23',
                 'adaptive_kdv_n64_b4096', 'adaptive_ks_n256_b1024',
                 'tower_k7_b4096', 'tower_f64_b4096', 'tower_k7f64_b4096', 'tower_k3_b4096',
-                'wide_ks_g9_b4096', 'burgers_b256', 'one_layer_b4096')
+                'wide_ks_g9_b4096', 'burgers_b256', 'one_layer_b4096',
+                # round 6: like-for-like partners of the adaptive / fixed-step KS legs, the
+                # production integrator on a small ensemble, the WENO5 exact solver
+                'adaptive_ks_n256_b8192', 'ks_n256_b1024', 'adaptive_rk23_b256',
+                'weno_exact_n512_b2048')
 
 
 def parse_args(argv=None):
@@ -841,6 +845,51 @@ def _adaptive_config(args, name='adaptive_rk23', batch=4096, t_end=1.0, unique=N
   return name, result
 
 
+def _weno_exact_config(args, n=512, batch=2048, t_end=0.5):
+  """The fine-grid exact Burgers solver (integrate.WENODifferentiator, integrate.py:124-140;
+  what scripts/create_exact_data.py maps over seeds): WENO5 + Godunov flux, per-seed forcing,
+  SciPy-RK23 semantics per sample in one launch of csrc/rhs_weno.h (one wavefront per
+  sample).  VALU-bound: no matrix work; ~450 VALU instructions per grid-point-evaluation,
+  half of them the 21 correctly rounded float32 divisions of the nonlinear weights."""
+  import torch
+  from ddd1d_amd import equations, model as model_lib
+  eqs = [equations.GodunovBurgersEquation(n, random_seed=s) for s in range(batch)]
+  model = model_lib.BaselineModel(eqs[0], 3, weno=True)
+  model.set_forcing(model_lib.forcing_from_equations(eqs))
+  ic = model_lib.batched_forcing_parameters([s + (1 << 20) for s in range(batch)], nparams=10)
+  x = eqs[0].grid.solution_x
+  y0 = np.sum(ic['a'][..., None] * np.sin(
+      2 * np.pi * ic['k'][..., None] * x / eqs[0].grid.period + ic['phi'][..., None]), axis=1)
+  y0d = torch.from_numpy(y0.astype(np.float64)).cuda()
+  times = np.linspace(0.0, t_end, 3)
+  model.integrate_adaptive(y0d, times)
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  kernel_ms, launches = 0.0, 0
+  while kernel_ms < args.config_timed_ms:
+    e0.record()
+    y, nfev, status = model.integrate_adaptive(y0d, times)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms += e0.elapsed_time(e1)
+    launches += 1
+  nfev = nfev.cpu().numpy().astype(np.int64)
+  evals = float(nfev.sum()) * n
+  result = {
+      'workload': 'GodunovBurgers N={} (the reference\'s exact grid), WENO5 + Godunov flux, per-seed '
+                  'forcing, batch {}, solve_ivp-RK23 semantics per sample, t in [0, {:g}], {} '
+                  'launches'.format(n, batch, t_end, launches),
+      'value': evals * launches / (kernel_ms * 1e-3), 'unit': 'grid-point-evaluations/s',
+      'nfev_min': int(nfev.min()), 'nfev_max': int(nfev.max()),
+      'samples_finished': int((status.cpu().numpy() == 0).sum()),
+      'kernel_ms_per_launch': kernel_ms / launches, 'kernel': model.kernel_name,
+      'state_dtype': 'float64', 'bound': 'valu', 'finite': bool(torch.isfinite(y).all()),
+      'round5_generic_kernel': 4.77e9,
+  }
+  model.close()
+  return 'weno_exact_n512_b2048', result
+
+
 def extra_configs(args, lib, world):
   """The rest of the contract, measured in the same run at N = 1."""
   wanted = (CONFIG_NAMES if args.configs == 'all' else
@@ -929,6 +978,21 @@ def extra_configs(args, lib, world):
         key, val = _differentiator_config(_variant(args, **base))
       elif name == 'adaptive_rk23':
         key, val = _adaptive_config(_variant(args, **base))
+      elif name == 'adaptive_rk23_b256':
+        key, val = _adaptive_config(_variant(args, **base), name, 256)
+      elif name == 'adaptive_ks_n256_b8192':
+        # the adaptive leg at the fixed-step leg's batch: 16 rounds of workgroups instead of
+        # two, so the spread of the per-sample evaluation counts no longer shows as a tail
+        key, val = _adaptive_config(_variant(args, **dict(base, equation='ks', num_points=256)),
+                                    name, 8192, t_end=0.02, unique=256)
+      elif name == 'ks_n256_b1024':
+        # ... and the fixed-step kernel at the adaptive leg's batch (two workgroups per CU)
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'KS N=256, conv-net stencils, batch 1024 (the batch of the '
+            'adaptive_ks_n256_b1024 leg: one round of two workgroups per CU), midpoint', 1024,
+            **dict(base, equation='ks', num_points=256, steps=400))
+      elif name == 'weno_exact_n512_b2048':
+        key, val = _weno_exact_config(args)
       elif name == 'adaptive_kdv_n64_b4096':
         key, val = _adaptive_config(_variant(args, **dict(base, equation='kdv')), name, 4096,
                                     t_end=0.2, unique=1024)

@@ -25,7 +25,9 @@ constexpr int kInMax = 8;     // widest per-derivative null space (G - rank)
 // (capi.hip: pack_mfma_weights).  Powers of two commute with every rounding of the fma
 // chains, so the finite results are the bits of max(x, 0) for activations in
 // [2^(-126 + kReluShift), 2^kReluShift] -- beyond 1.8e19 a state has diverged, below
-// 2e-19 an activation contributes nothing float32 can see.  NaN -> 0 like v_max (DX10 clamp).
+// 2e-19 an activation contributes nothing float32 can see.  NaN -> 0 like v_max (DX10 clamp):
+// rhs_mfma.h::eval_rhs re-creates the NaNs a propagating relu would have passed on (one
+// v_cmp per evaluation; the rest only when a state holds a NaN).
 // 64 relu instructions per wave-evaluation become 32 (profiles/r5_valu_census.txt).
 #ifndef DDD_RELU_CLAMP
 #define DDD_RELU_CLAMP 1   // A/B (profiles/r5_ablation.txt): 0 = one v_max_f32 per element, unscaled weights
@@ -197,8 +199,11 @@ struct SubstepArgs {
 
 __device__ __forceinline__ float apply_activation(float x, int act) {
   switch (act) {
-    case ACT_RELU: return fmaxf(x, 0.0f);
-    case ACT_RELU6: return fminf(fmaxf(x, 0.0f), 6.0f);
+    // (compare + select, not fmaxf: maxNum(NaN, 0) = 0 would stop a NaN that np.maximum /
+    // Eigen's relu -- and therefore the reference -- pass on; divergence must reach the caller
+    // as NaN at the grid points the reference marks, integrate.py:161-167)
+    case ACT_RELU: return x < 0.0f ? 0.0f : x;
+    case ACT_RELU6: return x < 0.0f ? 0.0f : (x > 6.0f ? 6.0f : x);
     case ACT_TANH: return tanhf(x);
     case ACT_SOFTPLUS: return (x > 0.0f ? x : 0.0f) + log1pf(expf(-fabsf(x)));
     case ACT_ELU: return x > 0.0f ? x : expm1f(x);

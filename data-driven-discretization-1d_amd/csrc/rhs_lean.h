@@ -46,11 +46,18 @@ struct Shared {
 };
 static_assert(sizeof(Shared) <= 8 * 1024, "LDS per wavefront: 20 wavefronts per CU fit 160 KB");
 
+// stencil-column pairs carried (kGP) for a stencil of G points
+inline int column_pairs(int G) { return G <= 6 ? 3 : 4; }
+
 // Models this kernel carries (checked on the host: capi.hip launch_integrate).
 inline bool supports(const DevParams& p) {
   if (!(p.fixed || p.linear_taps > 0) || p.weno) return false;
   if (p.N < 8 || p.N > 64 || 64 % p.N != 0) return false;
   if (p.G < 1 || p.G > kGMax || p.G > p.N || p.D < 1 || p.D > kMaxDerivs) return false;
+  // the kernel reads 2 column_pairs(G) window entries at offsets g - G / 2: they must stay
+  // inside the 4-point halo (G = 1: offsets 0 .. 5 would leave the sample's row -- 0 x the
+  // neighbour's halo, or never-written LDS, is NaN if that happens to hold one)
+  if (2 * column_pairs(p.G) - 1 - (p.G >> 1) > kHalo || (p.G >> 1) > kHalo) return false;
   if (p.linear_taps > 0 && (p.linear_taps > 7 || p.D > 3 || p.target != TARGET_COEFFICIENTS))
     return false;
   if (p.fixed && p.target != TARGET_COEFFICIENTS) return false;
@@ -60,8 +67,6 @@ inline bool supports(const DevParams& p) {
   }
   return true;
 }
-// stencil-column pairs carried (kGP) for a stencil of G points
-inline int column_pairs(int G) { return G <= 6 ? 3 : 4; }
 
 // Wavefronts per SIMD an instantiation is compiled for: the model's registers
 // (2 kGP kD (kK + 1)) leave room for four (<= 128 VGPRs: an ensemble of 4 096 N = 64 samples

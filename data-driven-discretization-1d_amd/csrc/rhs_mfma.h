@@ -26,6 +26,10 @@
 //
 // f32-input MFMA is bit-for-bit an fmaf chain in k order, so the arithmetic is
 // IEEE float32 like the reference's TF graph; only the summation order differs.
+// Two deliberate deviations, both documented where they live: tanh is fast_tanh (one
+// v_exp + one v_rcp, |error| <= 2e-7 absolute and <= 2e-7 relative, not the library's
+// 1-ulp tanhf), and relu is a clamp that maps NaN to 0 -- eval_rhs restores the NaNs the
+// reference's relu would have propagated (see "NaN through relu" there).
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -145,6 +149,9 @@ struct Shared {
   float fk[kFkMax];               // per (sample, k): sums of pm over modes with that k
   // [0,4): bias rows [d][stencil]; then one null-space row per output channel
   float tab[tab_rows(kWide) * flavour_stencil(kWide)];
+  // multi-wave groups: "some state of this group held a NaN" (eval_rhs: NaN through relu);
+  // sticky for the launch -- a NaN state stays NaN --, cleared by setup_weights
+  int nan_flag;
 };
 static_assert(sizeof(Shared<256>) <= 80 * 1024, "2 x 256-row workgroups per CU");
 static_assert(sizeof(Shared<64>) <= 20 * 1024, "8 x 64-row workgroups per CU");
@@ -432,9 +439,16 @@ __device__ __forceinline__ void load_hidden(const DevParams& p, int hidden_index
 #define DDD_MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32((A), (B), (C), 0, 0, 0)
 
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -2.885390081777927f);   // exp(-2 |x|)
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2 |x|)
   const float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-  return copysignf(q, x);
+  // |x| < 2^-4: 1 - t cancels (the 2e-7 ABSOLUTE bound of the quotient is 2e-7 / |x|
+  // relative: 2e-5 at 1e-2, and results quantised to 6e-8 below 1e-6; tf.tanh keeps
+  // relative accuracy).  There the odd Taylor polynomial
+  // |x| (1 - x^2 / 3 + 2 x^4 / 15) is within 4e-9 relative (next term 17 x^6 / 315).
+  const float x2 = x * x;
+  const float poly = ax * fmaf(x2, fmaf(x2, 2.0f / 15.0f, -1.0f / 3.0f), 1.0f);
+  return copysignf(ax < 0.0625f ? poly : q, x);
 }
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
@@ -470,10 +484,12 @@ __device__ __forceinline__ void activate16(f32x16& acc, int act) {
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
   } else if (act == ACT_TANH) {
     // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|): one v_exp_f32 and one v_rcp_f32
-    // (seven instructions) instead of the library's ~30 per element -- 192 elements per lane
-    // and evaluation in a four-layer net.  Absolute error <= 2e-7 (argument rounding 1.7e-7 x
-    // t <= 0.37, one ulp each of exp2 and rcp on values <= 1, two roundings), measured
-    // against float64 tanh in tests/test_cpu_mfma_emulation.py; NaN propagates, +-Inf -> +-1.
+    // (+ a three-term polynomial selected below |x| = 1/16: thirteen instructions) instead of
+    // the library's ~30 per element -- 192 elements per lane and evaluation in a four-layer
+    // net.  Absolute error <= 2e-7 (argument rounding 1.7e-7 x t <= 0.37, one ulp each of exp2
+    // and rcp on values <= 1, two roundings) AND relative error <= 2e-7 (the polynomial branch),
+    // measured against float64 tanh in tests/test_cpu_mfma_emulation.py; NaN propagates,
+    // +-Inf -> +-1.
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = fast_tanh(acc[r]);
   } else if (act == ACT_SOFTPLUS) {
@@ -1263,6 +1279,34 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   const int tid = opaque(group_tid<kRows, kWR>());
   const Lane ln = make_lane<kRows, kWR>(p, batch, tid, group < 0 ? (int)blockIdx.x : group);
   if (ln.owner) sm.u[ln.row] = u;
+  // ---- NaN through relu.  np.maximum / Eigen's relu pass a NaN on, so in the reference
+  // a NaN at grid point i makes the net's whole receptive field NaN: coefficients, hence
+  // derivatives, at x with i in [x - L (K / 2), x + L (K - 1 - K / 2)].  Here relu is a clamp
+  // (v_pk_add clamp / v_max / fmin(fmax)) that maps NaN to 0, and only the stencil's own
+  // reach would see the NaN.  The reference's mask is restored explicitly: ONE v_cmp per
+  // evaluation finds whether any state of the group is NaN (a ballot; multi-wave groups
+  // share a sticky LDS flag), and only then -- a diverged sample -- every lane looks for a
+  // NaN in its receptive field and replaces the net's outputs by NaN, from where it flows
+  // through projection, stencil apply, equation of motion and flux difference exactly as
+  // in the reference (tests/test_gpu_rhs.py::test_nan_mask_equals_the_oracles).
+  const bool clamps_nan = !fixed && (act == ACT_RELU || act == ACT_RELU6);   // wave-uniform
+  if (clamps_nan && !kOneWave) {
+    if (__builtin_amdgcn_ballot_w64(u != u) != 0 && ln.lane == 0) sm.nan_flag = 1;
+  }
+  const auto nan_in_receptive_field = [&]() -> bool {   // (the rare path)
+    const int n = p.N, lk = p.K >> 1;                  // layers.pad_periodic(center): K / 2 on the left
+    int span = p.L * (p.K - 1);
+    span = span < n - 1 ? span : n - 1;
+    int q = (ln.pos - p.L * lk) % n;
+    q = q < 0 ? q + n : q;
+    bool hit = false;
+    for (int i = 0; i <= span; ++i) {
+      const float v = sm.u[ln.base + q];
+      hit = hit || (v != v);
+      q = q + 1 == n ? 0 : q + 1;
+    }
+    return hit;
+  };
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][TW::kK];
@@ -1314,6 +1358,14 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // Four-wave groups must read them now (other waves rewrite sm.u as soon as
   // they enter the next evaluation); a one-wave group reads them in the
   // epilogue instead and saves 8 registers across the conv tower.
+  // multi-wave groups decide now: a faster wavefront rewrites sm.u as soon as it enters the
+  // next evaluation (one-wave groups decide where the net's outputs are consumed: nothing
+  // is carried across the tower)
+  bool nan_any = false, poisoned = false;
+  if (clamps_nan && !kOneWave) {
+    nan_any = __builtin_amdgcn_readfirstlane(sm.nan_flag) != 0;
+    if (nan_any) poisoned = nan_in_receptive_field();
+  }
   float pch[kGW];
   const int gl = nG >> 1;
   if (!kOneWave) {
@@ -1537,6 +1589,17 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     group_barrier<kRows, kWR>();   // all patch reads done before the next evaluation rewrites sm.u
   }
 
+  if (clamps_nan) {   // NaN through relu (top of this function)
+    if (kOneWave) {
+      nan_any = __builtin_amdgcn_ballot_w64(u != u) != 0;
+      if (nan_any) poisoned = nan_in_receptive_field();
+    }
+    if (nan_any) {   // wave-uniform, rare
+      const float qnan = __int_as_float(0x7fc00000);
+#pragma unroll
+      for (int c = 0; c < kCh; ++c) net[c] = poisoned ? qnan : net[c];
+    }
+  }
   // ---- projection onto the accuracy-constrained stencils + stencil apply -----
   // coeff = bias + net[start:stop] @ nullspace   (polynomials.py:275-277)
   // deriv = sum_i coeff[i] * patch[i]            (model.py:548)
@@ -1960,6 +2023,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
     sm.pm[i] = make_float2(0.0f, 0.0f);
+  if (tid == 0) sm.nan_flag = 0;
 #ifdef DDD_PROBES
   if (res.probe_stamp != nullptr && tid == 0)
     *res.probe_stamp = __builtin_amdgcn_s_memrealtime();

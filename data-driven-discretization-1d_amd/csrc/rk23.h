@@ -86,7 +86,11 @@ struct Control {
     if (d1 <= 1e-15 && d2 <= 1e-15) {
       h1 = h0 * 1e-3 > 1e-6 ? h0 * 1e-3 : 1e-6;
     } else {
-      h1 = pow(0.01 / (d2 > d1 ? d2 : d1), 1.0 / 3.0);   // error estimator order 2
+      // (0.01 / max(d1, d2)) ** (1 / (error_estimator_order + 1)), order 2: the cube root
+      // (as safety_factor below; the device library's pow is a 17-coefficient polynomial
+      // whose constants the compiler parked in scratch inside the adaptive kernels' loop,
+      // profiles/r5_spill_table.txt; differs from pow(x, 0.3333333333333333) by a few ulp)
+      h1 = cbrt(0.01 / (d2 > d1 ? d2 : d1));
     }
     h_abs = 100.0 * h0;
     if (h1 < h_abs) h_abs = h1;

@@ -182,6 +182,11 @@ class Equation(object):
     raise NotImplementedError
 
   def to_exact(self) -> 'Equation':
+    # (an equation that already is its exact form: the object itself -- equations are
+    # immutable, and rebuilding one re-seeds a RandomState, ~0.1 ms per sample that
+    # integrate_exact_batch would pay for every seed of a batch)
+    if type(self) is self.exact_type():
+      return self
     return self.exact_type()(**self.params())
 
   def to_conservative(self) -> 'Equation':

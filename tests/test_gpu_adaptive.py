@@ -10,7 +10,8 @@ right-hand side -- SciPy is the reference's own third-party integrator."""
 import numpy as np
 import pytest
 
-from helpers import FLOOR_CEILING, batch_forcing, make_model, oracle, random_phase_ic, rel_err
+from helpers import (FLOOR_CEILING, assert_near_truth, batch_forcing, make_model, oracle,
+                     random_phase_ic, rel_err)
 from ddd1d_amd import integrate, model as model_lib
 
 pytestmark = pytest.mark.gpu
@@ -72,6 +73,9 @@ def _check(model, y0, times, forcing=None, max_step=0.01, tol=TOL, samples=None,
       print('sample {}: err {:.1e}, float32 noise floor of the reference run {:.1e}'
             .format(b, err, floor))
       assert floor < FLOOR_CEILING and err < 4 * floor, (b, err, floor)
+      # ... and the device run is as close to the float64-apply run as the reference run is
+      # (x TRUTH_RATIO), not merely inside the triangle bound
+      assert_near_truth(y[both, b], truth[both], floor, 'adaptive sample %d' % b)
   for b in hip_samples:
     want, want_nfev = _scipy_over_hip_rhs(model, y0[b], times, _one(forcing, b), max_step,
                                           **solver)

@@ -39,7 +39,8 @@ def test_weno_rhs_vs_oracle(cls_name, n):
   print(cls_name, n, 'rel err {:.2e}'.format(err))
   # 1e-5, or 4 x the float32 oracle's measured distance from the all-float64
   # evaluation of the same formulas (KS: u_xxx stencils cancel ~1e3-fold)
-  assert err < measured_bound(want, baseline_rhs_f64(spec, y), TOL, cls_name + ' WENO rhs:')
+  assert err < measured_bound(want, baseline_rhs_f64(spec, y), TOL, cls_name + ' WENO rhs:',
+                              got=got)
   derivs = model.space_derivatives(y).cpu().numpy()
   np.testing.assert_allclose(derivs[..., 0], np.roll(oracle.weno_reconstruct_left(y), 1, axis=-1),
                              rtol=0, atol=TOL * np.abs(y).max())
@@ -66,7 +67,8 @@ def test_weno_differentiator_vs_reference_trajectories(exact, cls_name, n, seed)
          if eq.has_time_dependent_forcing else None)
   f32_rhs = oracle.time_derivative(spec, 0.2, probe[None], None if frc is None else
                                    {k: v[None] for k, v in frc.items()})[0]
-  assert rel_err(got_rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, base + ' rhs:')
+  assert rel_err(got_rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, base + ' rhs:',
+                                                         got=got_rhs)
   ds = integrate.integrate_weno(eq, times=exact[base + '/times'])
   got = np.asarray(ds.data_vars['y'][1] if isinstance(ds.data_vars['y'], tuple)
                    else ds['y'].data)

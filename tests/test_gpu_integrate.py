@@ -383,7 +383,7 @@ def test_integrate_baseline_vs_reference_golden(golden, cls_name, n, rf, seed, a
   f32_rhs = oracle.time_derivative(spec, 0.1, y_probe[None], None if frc is None else
                                    {k: v[None] for k, v in frc.items()})[0]
   from helpers import measured_bound
-  assert rel_err(rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, key + ' rhs:')
+  assert rel_err(rhs, want_rhs) < measured_bound(f32_rhs, want_rhs, TOL, key + ' rhs:', got=rhs)
 
 
 def test_integrate_batch_matches_per_sample_scipy():
