@@ -88,7 +88,7 @@ CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burger
                 'wide_ks_g9_b4096', 'burgers_b256', 'one_layer_b4096',
                 # round 6: like-for-like partners of the adaptive / fixed-step KS legs, the
                 # production integrator on a small ensemble, the WENO5 exact solver
-                'adaptive_ks_n256_b8192', 'ks_n256_b1024', 'adaptive_rk23_b256',
+                'adaptive_ks_n256_b8192', 'ks_n256_b1024', 'adaptive_rk23_b256', 'burgers_b512',
                 'weno_exact_n512_b2048')
 
 
@@ -968,12 +968,14 @@ def extra_configs(args, lib, world):
             'its model_kwargs): coefficients affine in the 5 neighbouring values, folded on the '
             'host; 111 FMA per grid point and evaluation, no matrix work', 4096,
             **dict(base, hparams=json.dumps({'num_layers': 1}), steps=1000))
-      elif name == 'burgers_b256':
+      elif name in ('burgers_b256', 'burgers_b512'):
+        small = 256 if name == 'burgers_b256' else 512
         key, val = _fixed_step_config(
-            args, lib, world, name, 'the headline model on a SMALL ensemble (256 samples: a '
-            'quarter of the SIMDs would hold a 64-row wavefront): every sample on two 32-row '
-            'wavefronts, output layer split by channel groups', 256,
-            **dict(base, steps=1000))
+            args, lib, world, name, 'the headline model on a SMALL ensemble ({} samples: a '
+            '{} of the SIMDs would hold a 64-row wavefront): every sample on FOUR 16-row '
+            'wavefronts, all layers on 16x16x4 MFMAs (rhs_mfma.h kQuad; round 5: two 32-row '
+            'wavefronts, 31.6 % at 256)'.format(small, 'quarter' if small == 256 else 'half'),
+            small, **dict(base, steps=1000))
       elif name == 'differentiator_b1':
         key, val = _differentiator_config(_variant(args, **base))
       elif name == 'adaptive_rk23':

@@ -23,7 +23,7 @@ MODEL_TARGETS = {'coefficients': 0, 'space_derivatives': 1,
                  'time_derivative': 2, 'flux': 3}
 SCHEMES = {'euler': 0, 'midpoint': 1, 'bs3': 2, 'rk23': 2, 'rk4': 3}
 KERNELS = {'auto': 0, 'generic': 1, 'mfma': 2, 'mfma64': 3, 'mfma256': 4,
-           'mfma64w32': 5}
+           'mfma64w32': 5, 'mfma64w16': 6}
 LAUNCH_MODES = {'persistent': 0, 'per_substep': 1, 'per_step': 2}
 
 

@@ -190,6 +190,7 @@ struct ddd_model {
   bool last_launch_streamed = false; // the most recent launch was the streaming fixed-stencil kernel
   bool last_launch_split = false;    // ... the persistent integrator with two 32-row wavefronts per sample
   bool last_launch_lean = false;     // ... the lane == grid point kernel of rhs_lean.h
+  bool last_launch_quad = false;     // ... four 16-row wavefronts per group (rhs_mfma.h kQuad)
   int last_batch = 0;                // batch of the most recent launch (kernel_name)
   int64_t fma_per_point = 0;
   // device allocations
@@ -202,6 +203,7 @@ struct ddd_model {
   float* d_w_final4 = nullptr;
   float* d_w_final4_rt = nullptr;
   float* d_w_final4_split = nullptr;
+  float* d_w_quad = nullptr;
   bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
   bool split_auto = true;            // small ensembles: two 32-row wavefronts per sample (kSplit)
   int tower_k = 5, tower_cb = 1;     // conv tower the MFMA kernels carry the net in (rhs_mfma.h Tower)
@@ -641,6 +643,50 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
           m->dp.w_final4_split = m->d_w_final4_split;
         }
       }
+      // ... and the whole net for the integrators on FOUR 16-row wavefronts (rhs_mfma.h
+      // kQuad), every layer as v_mfma_f32_16x16x4_f32 A operands: lane l supplies
+      // W[out = l & 15][reduction slot sg = l >> 4] of a step.  Three-layer nets only
+      // (the per-equation kernels'), <= 16 output channels in the renumbering of w_final4.
+      if (dp.L == 3 && m->dp.fin4_groups <= 4) {
+        using namespace ddd::mfma;
+        const float* w = m->spec_folded ? wf.data() : w_nat;
+        const float* b = m->spec_folded ? bf.data() : b_nat;
+        const int cout_n = m->spec_folded ? fold_cols : dp.C_out;
+        const int n_ch = m->spec_folded ? dp.D * dp.G : dp.C_out;
+        std::vector<float> quad((size_t)kQuadRows * 64, 0.0f);
+        const float* w0 = weights + net.w_off[0];   // [5][1][32]
+        const float* b0 = weights + net.b_off[0];
+        const float* w1 = weights + net.w_off[1];   // [5][32][32]
+        const float* b1 = weights + net.b_off[1];
+        for (int chh = 0; chh < 2; ++chh)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int sg = lane >> 4, cout = 16 * chh + (lane & 15);
+            // input layer: step 0 = taps 0..3, step 1 = tap 4, bias, 0, 0 (input_layer's k order)
+            quad[(size_t)(chh * kQuadInSteps + 0) * 64 + lane] = dn * w0[sg * 32 + cout];
+            quad[(size_t)(chh * kQuadInSteps + 1) * 64 + lane] =
+                sg == 0 ? dn * w0[4 * 32 + cout] : sg == 1 ? dn * b0[cout] : 0.0f;
+            // hidden layer: step 8 tap + i, slot sg -> cin = (sg >> 1) + 16 (sg & 1) + 2 i:
+            // per tap c = 0, 16, 1, 17, ... -- hidden_layer's order (s = 16 tap + jj, half = l >> 5)
+            float* hid = quad.data() + (size_t)(2 * kQuadInSteps + chh * kQuadHidSteps) * 64;
+            for (int s2 = 0; s2 < 40; ++s2) {
+              const int tap = s2 / 8, i = s2 % 8;
+              const int cin = (sg >> 1) + 16 * (sg & 1) + 2 * i;
+              hid[(size_t)s2 * 64 + lane] = w1[(tap * 32 + cin) * 32 + cout];
+            }
+            hid[(size_t)40 * 64 + lane] = sg == 0 ? dn * b1[cout] : 0.0f;
+          }
+        // output layer: step s2, slot sg -> k = 4 s2 + sg in natural order (final_layer4's), k = 160: bias
+        float* fin = quad.data() + (size_t)(2 * kQuadInSteps + 2 * kQuadHidSteps) * 64;
+        for (int s2 = 0; s2 < kQuadFinSteps; ++s2)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int k = 4 * s2 + (lane >> 4), ch = lane & 15;
+            if (ch >= n_ch || ch >= cout_n || k > 160) continue;
+            fin[(size_t)s2 * 64 + lane] = k < 160 ? up * w[(size_t)k * cout_n + ch] : b[ch];
+          }
+        rc = upload(quad, &m->d_w_quad);
+        if (rc) return rc;
+        m->dp.w_quad = m->d_w_quad;
+      }
     }
   }
   return DDD_OK;
@@ -810,6 +856,7 @@ MfmaGeometry mfma_geometry(const ddd_model* m, int batch) {
   if (m->force_rows == 256 || !fits64) return {256, 64};
   if (m->force_rows == 64) return {64, 64};
   if (m->force_rows == 32 && !m->wide && !m->big()) return {64, 32};   // (no wide / other-tower split)
+  if (m->force_rows == 16 && !m->wide && !m->big()) return {64, 16};   // (launch_integrate alone honours it)
   // Two 32-row wavefronts per sample are never the geometry of the fused substep or
   // the adaptive kernels; launch_integrate alone switches small float32 ensembles to
   // the split integrators (rhs_mfma.h kSplit), where the measurement says it pays.
@@ -900,7 +947,8 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
       dp.frc += (size_t)sample0 * dp.P;
       dp.runs += (size_t)sample0 * 8;
     }
-    const MfmaGeometry geo = mfma_geometry(m, a.batch);
+    MfmaGeometry geo = mfma_geometry(m, a.batch);
+    if (geo.wave_rows == 16) geo = {64, 64};   // (four-wavefront groups: persistent integrators only)
     const int spg = geo.rows / m->dp.N;
     const int blocks = (a.batch + spg - 1) / spg;
     // per-equation instantiations for the plain substep (no derivative views)
@@ -968,6 +1016,7 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   // integrate.py:154 -- in the one-wave geometry (launch.h)
   int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m, kRows) : -1;
   if (kWR == 32 && !f64 && m->dp.w_final4_split != nullptr) eq = spec_equation(m, kRows);
+  if (kWR == 16) eq = (!f64 && m->dp.w_quad != nullptr) ? spec_equation(m, kRows) : -1;
   bool traced = false;
 #ifdef DDD_PROBES
   if (a.trace != nullptr) {
@@ -979,7 +1028,8 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
 #endif
 #define DDD_SPEC_CASE(EQ)                                                              \
   case EQ:                                                                             \
-    if (kWR == 32) ddd::launch::integrate_split_spec<EQ>(m->dp, a, blocks, stream);    \
+    if (kWR == 16) ddd::launch::integrate_quad_spec<EQ>(m->dp, a, blocks, stream);     \
+    else if (kWR == 32) ddd::launch::integrate_split_spec<EQ>(m->dp, a, blocks, stream); \
     else ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); \
     return;
   switch (eq) {
@@ -1051,6 +1101,7 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   a.ablate = g_debug.ablate;
 #endif
   m->last_launch_split = false;
+  m->last_launch_quad = false;
   if (m->kernel == DDD_KERNEL_MFMA && std::is_same<ST, float>::value && !m->explicit_kernel &&
       !g_debug.no_lean && launch_lean(m, a, stream)) {
     // fixed stencils / one-layer nets, float32 state, whole samples per wavefront: the
@@ -1069,10 +1120,22 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
       // the SIMDs busy), B = 512: 0.97 x, B = 1024: 0.89 x (two coupled wavefronts per SIMD lose to one
       // free-running one) -- so only below three eighths of a wavefront per SIMD
       const int spg = 64 / m->dp.N;
-      if (8 * ((a.batch + spg - 1) / spg) <= 3 * device_simds()) geo = {64, 32};
+      const int groups = (a.batch + spg - 1) / spg;
+      if (8 * groups <= 3 * device_simds()) geo = {64, 32};
+      // ... and FOUR 16-row wavefronts per group (kQuad: every layer on 16x16x4 MFMAs, one
+      // group on the four SIMDs of a CU) while that leaves at most two wavefronts per SIMD
+      // (measured, profiles/r6_ablation.txt)
+      if (m->dp.w_quad != nullptr && 2 * groups <= device_simds()) geo = {64, 16};
     }
+    // an explicit DDD_KERNEL_MFMA_ROWS64_W16 / _W32 where the model has no such kernel (float64
+    // state, no per-equation specialisation): the one-wavefront geometry
+    if (geo.rows == 64 && geo.wave_rows == 16 &&
+        !(std::is_same<ST, float>::value && m->dp.w_quad != nullptr && spec_equation(m, 64) >= 0))
+      geo = {64, 64};
     m->last_launch_split = geo.rows == 64 && geo.wave_rows == 32;
+    m->last_launch_quad = geo.rows == 64 && geo.wave_rows == 16;
     if (geo.rows == 64 && geo.wave_rows == 64) launch_mfma_integrate<64, 64, ST>(m, a, stream);
+    else if (geo.rows == 64 && geo.wave_rows == 16) launch_mfma_integrate<64, 16, ST>(m, a, stream);
     else if (geo.rows == 64) launch_mfma_integrate<64, 32, ST>(m, a, stream);
     else launch_mfma_integrate<256, 64, ST>(m, a, stream);
   } else if (use_weno_kernel(m)) {
@@ -1574,7 +1637,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_w_final4_split); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
+  free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_w_final4_split); free_dev(m->d_w_quad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
   for (auto& slot : m->time_slot) {
@@ -2267,6 +2330,7 @@ int ddd_set_kernel(ddd_model* m, int kind) {
     case DDD_KERNEL_MFMA_ROWS64:
     case DDD_KERNEL_MFMA_ROWS256:
     case DDD_KERNEL_MFMA_ROWS64_W32:
+    case DDD_KERNEL_MFMA_ROWS64_W16:
       if (!m->mfma_ok)
         return fail(DDD_ERR_UNSUPPORTED, "MFMA path unavailable for this model: %s",
                     m->mfma_reason.c_str());
@@ -2274,7 +2338,12 @@ int ddd_set_kernel(ddd_model* m, int kind) {
         return fail(DDD_ERR_UNSUPPORTED,
                     "the two-wave split exists for the 5-tap x 32-filter tower with stencils <= 8 "
                     "points / <= 16 channels only");
-      if ((kind == DDD_KERNEL_MFMA_ROWS64 || kind == DDD_KERNEL_MFMA_ROWS64_W32) &&
+      if (kind == DDD_KERNEL_MFMA_ROWS64_W16 && m->dp.w_quad == nullptr)
+        return fail(DDD_ERR_UNSUPPORTED,
+                    "four 16-row wavefronts per group exist for three-layer 5-tap x 32-filter nets "
+                    "with <= 16 output channels only");
+      if ((kind == DDD_KERNEL_MFMA_ROWS64 || kind == DDD_KERNEL_MFMA_ROWS64_W32 ||
+           kind == DDD_KERNEL_MFMA_ROWS64_W16) &&
           !(m->dp.N <= 64 && 64 % m->dp.N == 0))
         return fail(DDD_ERR_UNSUPPORTED,
                     "64-row workgroups need num_points to divide 64 (got %d)", m->dp.N);
@@ -2282,6 +2351,7 @@ int ddd_set_kernel(ddd_model* m, int kind) {
       m->explicit_kernel = true;
       m->force_rows = kind == DDD_KERNEL_MFMA_ROWS64 ? 64
                       : kind == DDD_KERNEL_MFMA_ROWS64_W32 ? 32
+                      : kind == DDD_KERNEL_MFMA_ROWS64_W16 ? 16
                       : kind == DDD_KERNEL_MFMA_ROWS256 ? 256 : 0;
       return DDD_OK;
     default:
@@ -2298,6 +2368,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   if (m->kernel != DDD_KERNEL_MFMA) return "generic";
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
+  if (m->last_launch_quad) return "mfma_f32_r64w16";
   return (geo.wave_rows == 32 || m->last_launch_split) ? "mfma_f32_r64w32" : "mfma_f32_r64";
 }
 

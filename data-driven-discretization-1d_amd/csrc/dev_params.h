@@ -103,6 +103,10 @@ struct DevParams {
   // kSplit): chunk 0 = groups [0, ceil(NG / 2)), chunk 1 = the rest, each packed on its own
   // (q = k * groups_of_chunk + g) in 24 quad-stored rows; null: no split kernels for this model
   const float* w_final4_split;
+  // four wavefronts per 64-row group (rhs_mfma.h kQuad): the A operands of the 16x16x4 layers,
+  // [2 channel halves][2] input rows, [2][41] hidden rows, [41] output rows of 64 lanes
+  // (lane l: W[out = l & 15][reduction slot l >> 4]); null: no such kernels for this model
+  const float* w_quad;
   // run-time-parameterised kernels: the live channel groups packed two by two
   // (pair gp: fin4_regs(2) rows for groups 2 gp, 2 gp + 1; an odd last group:
   // fin4_regs(1) rows), channels in natural / G d + g (folded) numbering; plain [rows][64]

@@ -25,6 +25,10 @@ void integrate_spec(int rows, bool f64, bool traced, const DevParams& p, const I
 template <int kEq>
 void integrate_split_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
                           hipStream_t stream);
+// ... on four 16-row wavefronts, every layer on 16x16x4 MFMAs (rhs_mfma.h kQuad; float32 state)
+template <int kEq>
+void integrate_quad_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
+                         hipStream_t stream);
 // grid: workgroups to launch (<= groups); every workgroup walks over groups.
 template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
@@ -47,7 +51,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
   template <> void adaptive_spec<EQ>(int, const DevParams&, const AdaptiveArgs&, int,          \
                                      hipStream_t);                                             \
   template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
-  template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t);
+  template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
+  template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t);
 DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
 DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
 #undef DDD_DECLARE_SPEC

@@ -47,6 +47,13 @@ void integrate_split_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, in
 }
 
 template <>
+void integrate_quad_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int blocks,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::integrate_kernel<64, 16, float, true, DDD_EQ>), dim3(blocks), dim3(256),
+                     0, stream, p, a);
+}
+
+template <>
 void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, int groups,
                           int grid, hipStream_t stream) {
   if (rows == 64)

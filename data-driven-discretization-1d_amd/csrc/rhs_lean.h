@@ -251,7 +251,10 @@ __global__ __launch_bounds__(64, (waves_per_simd(kK, kD, kGP))) void integrate_k
       for (int d = 0; d < kMaxDerivs; ++d) dv[d] = 0.0f;
       float pch[2 * kGP];
 #pragma unroll
-      for (int g = 0; g < 2 * kGP; ++g) pch[g] = win_u[kHalo + g - gl];   // (g >= G: times a zero)
+      // (columns g >= G carry a zero coefficient; they read the grid point itself -- offset
+      // 0 is inside every stencil -- so that 0 x NaN never marks a point the reference's
+      // stencil does not touch: integrate.py:161-167 signals divergence by NaN rows)
+      for (int g = 0; g < 2 * kGP; ++g) pch[g] = win_u[kHalo + (g < p.G ? g - gl : 0)];
 #pragma unroll
       for (int d = 0; d < kD; ++d) {
         float acc = 0.0f;

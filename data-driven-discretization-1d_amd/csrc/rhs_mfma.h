@@ -27,7 +27,7 @@
 // f32-input MFMA is bit-for-bit an fmaf chain in k order, so the arithmetic is
 // IEEE float32 like the reference's TF graph; only the summation order differs.
 // Two deliberate deviations, both documented where they live: tanh is fast_tanh (one
-// v_exp + one v_rcp, |error| <= 2e-7 absolute and <= 2e-7 relative, not the library's
+// v_exp + one v_rcp, |error| <= 2e-7 absolute and <= 3e-7 relative, not the library's
 // 1-ulp tanhf), and relu is a clamp that maps NaN to 0 -- eval_rhs restores the NaNs the
 // reference's relu would have propagated (see "NaN through relu" there).
 #pragma once
@@ -442,13 +442,16 @@ __device__ __forceinline__ float fast_tanh(float x) {
   const float ax = fabsf(x);
   const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2 |x|)
   const float q = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
-  // |x| < 2^-4: 1 - t cancels (the 2e-7 ABSOLUTE bound of the quotient is 2e-7 / |x|
+  // |x| < 1/4: 1 - t cancels (the 2e-7 ABSOLUTE bound of the quotient is 2e-7 / |x|
   // relative: 2e-5 at 1e-2, and results quantised to 6e-8 below 1e-6; tf.tanh keeps
   // relative accuracy).  There the odd Taylor polynomial
-  // |x| (1 - x^2 / 3 + 2 x^4 / 15) is within 4e-9 relative (next term 17 x^6 / 315).
+  // |x| (1 - x^2 / 3 + 2 x^4 / 15 - 17 x^6 / 315 + 62 x^8 / 2835) is within 1e-8 relative
+  // (next term 1382 x^10 / 155925); the quotient is within 2e-7 relative from 1/4 up.
   const float x2 = x * x;
-  const float poly = ax * fmaf(x2, fmaf(x2, 2.0f / 15.0f, -1.0f / 3.0f), 1.0f);
-  return copysignf(ax < 0.0625f ? poly : q, x);
+  const float poly =
+      ax * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.0f / 2835.0f, -17.0f / 315.0f), 2.0f / 15.0f),
+                         -1.0f / 3.0f), 1.0f);
+  return copysignf(ax < 0.25f ? poly : q, x);
 }
 
 __device__ __forceinline__ void activate16(f32x16& acc, int act) {
@@ -484,10 +487,10 @@ __device__ __forceinline__ void activate16(f32x16& acc, int act) {
     for (int r = 0; r < 16; ++r) acc[r] = fminf(fmaxf(acc[r], 0.0f), 6.0f);
   } else if (act == ACT_TANH) {
     // tanh(x) = sign(x) (1 - t) / (1 + t), t = exp(-2 |x|): one v_exp_f32 and one v_rcp_f32
-    // (+ a three-term polynomial selected below |x| = 1/16: thirteen instructions) instead of
+    // (+ a five-term polynomial selected below |x| = 1/4: fifteen instructions) instead of
     // the library's ~30 per element -- 192 elements per lane and evaluation in a four-layer
     // net.  Absolute error <= 2e-7 (argument rounding 1.7e-7 x t <= 0.37, one ulp each of exp2
-    // and rcp on values <= 1, two roundings) AND relative error <= 2e-7 (the polynomial branch),
+    // and rcp on values <= 1, two roundings) AND relative error <= 3e-7 (the polynomial branch),
     // measured against float64 tanh in tests/test_cpu_mfma_emulation.py; NaN propagates,
     // +-Inf -> +-1.
 #pragma unroll
@@ -665,6 +668,184 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
     if (kByteOffsets) store_tile32_at_bytes(out, st_off + t * 32 * kHS * 4, acc[t]);
     else store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
+}
+
+// ---------------------------------------------------------------------------
+// FOUR wavefronts per 64-row group (kRows = 64, kWR = 16; per-equation integrators): one
+// sample of a small ensemble on all four SIMDs of a CU.  The reference's callers integrate
+// tens to hundreds of samples (scripts/run_evaluation.py:212-221,
+// create_baseline_data.py:119-130); with one 64-row wavefront per sample three quarters of
+// the SIMDs idle at 256 samples, with two 32-row wavefronts (kSplit) half of them.
+//   * wavefront w = ph + 2 ch carries the 32 positions [32 ph, 32 ph + 32) x the 16 output
+//     channels [16 ch, 16 ch + 16) of the input and hidden layers on v_mfma_f32_16x16x4_f32
+//     (the same 32 FMA / cycle / SIMD as 32x32x2): 2 position tiles x 41 steps per hidden
+//     layer instead of 162 steps of 32x32x2;
+//   * the output layer also on 16x16x4: wavefront w computes all (<= 16) channels of ITS
+//     OWN 16 rows [16 w, 16 w + 16) -- the rows it carries through the VALU phases --, so
+//     the results return to lane == row through LDS inside the wavefront (no barrier);
+//   * every accumulation chain runs in the order of the one-wavefront kernel -- hidden
+//     layer: per tap c = 0, 16, 1, 17, ... (hidden_layer's step s = 16 tap + jj with
+//     half = l >> 5), i.e. reduction slots [2 i, 16 + 2 i, 2 i + 1, 17 + 2 i] of step
+//     8 tap + i; output layer: natural k = 32 tap + c --, so the bits are the
+//     one-wavefront kernel's (tests/test_gpu_integrate.py: assert_array_equal);
+//   * activations in LDS rows of 36 floats with channel c at float
+//     4 (4 (c >> 4) + (c & 3)) + ((c & 15) >> 2): the B operands of both layers are two
+//     aligned ds_read_b128 per tap (hidden layer, slot sg = l >> 4: blocks (sg & 1, sg >> 1)
+//     and (sg & 1, (sg >> 1) + 2), elements alternating; output layer: blocks (0, sg), (1, sg)).
+// A operands (capi.hip: pack_quad_weights): DevParams::w_quad = [2 ch][2] input rows,
+// [2 ch][41] hidden rows, [41] output rows of 64 lanes, lane l = W[out = l & 15][slot l >> 4].
+// ---------------------------------------------------------------------------
+#define DDD_MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
+constexpr int kQuadHidSteps = 41, kQuadFinSteps = 41, kQuadInSteps = 2;
+constexpr int kQuadRows = 2 * kQuadInSteps + 2 * kQuadHidSteps + kQuadFinSteps;   // rows of w_quad (4 + 82 + 41)
+__host__ __device__ constexpr int quad_channel_float(int c) {   // position of channel c in an LDS row
+  return 4 * (4 * (c >> 4) + (c & 3)) + ((c & 15) >> 2);
+}
+
+// relu etc. on one 16x16 tile (4 accumulator registers per lane)
+__device__ __forceinline__ void activate4(f32x4& acc, int act) {
+  if (act == ACT_RELU) {
+#if DDD_RELU_CLAMP
+#pragma unroll
+    for (int r = 0; r < 4; r += 2) {
+      f32x2 v{acc[r], acc[r + 1]}, y;
+      asm("v_pk_add_f32 %0, %1, 0 clamp" : "=v"(y) : "v"(v));
+      acc[r] = y[0];
+      acc[r + 1] = y[1];
+    }
+#else
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float y;
+      asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(acc[r]));
+      acc[r] = y;
+    }
+#endif
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = apply_activation(acc[r], act);
+  }
+}
+
+// D of a 16x16 tile -> LDS: lane l holds channels 16 ch + 4 (l >> 4) + r of position l & 15;
+// st_off = byte offset of (row, channel 16 ch + 4 (l >> 4)): r advances the block (16 bytes)
+__device__ __forceinline__ void store_tile16(float* out, int st_off, const f32x4& acc) {
+  char* o = reinterpret_cast<char*>(out) + st_off;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(o + 16 * r) = acc[r];
+}
+
+// input layer 1 -> 16 channels of this wavefront, two 16-position tiles
+//   step 0: slots = taps 0..3; step 1: tap 4, bias (against 1.0), 0, 0
+// in_off[t][0]: byte offset into Shared::un of tap (l >> 4)'s row, [t][1]: of tap 4's row
+__device__ __forceinline__ void input_layer_quad(const float* __restrict__ un, float* __restrict__ out,
+                                                 const float (&w)[kQuadInSteps],
+                                                 const int (&in_off)[2][2], const int (&st_off)[2],
+                                                 int act, int lane) {
+  const char* ub = reinterpret_cast<const char*>(un);
+  float b0[2], b1[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    b0[t] = *reinterpret_cast<const float*>(ub + in_off[t][0]);
+    const float tap4 = *reinterpret_cast<const float*>(ub + in_off[t][1]);
+    b1[t] = lane < 16 ? tap4 : 1.0f;   // (slots 2, 3 carry zero weights)
+  }
+  f32x4 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = DDD_MFMA16(w[0], b0[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = DDD_MFMA16(w[1], b1[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    activate4(acc[t], act);
+    store_tile16(out, st_off[t], acc[t]);
+  }
+}
+
+// hidden layer: this wavefront's 16 output channels x two 16-position tiles.
+// hid_off[t][tap]: byte offset of block (sg & 1, sg >> 1) of the tap's row (the second
+// block, (sg & 1, (sg >> 1) + 2), is 32 bytes on)
+__device__ __forceinline__ void hidden_layer_quad(const float* __restrict__ in, float* __restrict__ out,
+                                                  const float (&w)[kQuadHidSteps],
+                                                  const int (&hid_off)[2][kKW], const int (&st_off)[2],
+                                                  int act) {
+  const char* ib = reinterpret_cast<const char*>(in);
+  f32x4 acc[2];
+  float4 ca[2], cb[2], na[2], nb[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    ca[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][0]);
+    cb[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][0] + 32);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // the reads of tap 0
+#pragma unroll
+  for (int tap = 0; tap < kKW; ++tap) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      na[t] = ca[t]; nb[t] = cb[t];
+      if (tap + 1 < kKW) {
+        na[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][tap + 1]);
+        nb[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][tap + 1] + 32);
+      }
+    }
+    // steps 8 tap + i, i = 0..7: B = a.x, b.x, a.y, b.y, a.z, b.z, a.w, b.w; the two tiles
+    // alternate (two independent accumulators: the 16x16x4 issues every 32 cycles, a
+    // dependent one every 40)
+#define DDD_QSTEP(I, V)                                                          \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                \
+      acc[t] = DDD_MFMA16(w[8 * tap + (I)], (V), acc[t]);
+    DDD_QSTEP(0, ca[t].x) DDD_QSTEP(1, cb[t].x) DDD_QSTEP(2, ca[t].y) DDD_QSTEP(3, cb[t].y)
+    DDD_QSTEP(4, ca[t].z) DDD_QSTEP(5, cb[t].z) DDD_QSTEP(6, ca[t].w) DDD_QSTEP(7, cb[t].w)
+#undef DDD_QSTEP
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
+    if (tap + 1 < kKW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // reads of tap + 1 first
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                      // the 16 MFMAs of this tap
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t] = DDD_MFMA16(w[40], 1.0f, acc[t]);   // bias: slot 0 carries b[out]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    activate4(acc[t], act);
+    store_tile16(out, st_off[t], acc[t]);
+  }
+}
+
+// output layer for this wavefront's own 16 rows: D[channel 4 (l >> 4) + r][row l & 15],
+// natural reduction order k = 32 tap + c, 4 k per step (slot sg: c = sg + 4 i).
+// fin_off[tap]: byte offset of block (0, sg) of the tap's row (block (1, sg): 64 bytes on)
+__device__ __forceinline__ f32x4 final_layer_quad(const float* __restrict__ in,
+                                                  const float (&w)[kQuadFinSteps],
+                                                  const int (&fin_off)[kKW]) {
+  const char* ib = reinterpret_cast<const char*>(in);
+  f32x4 acc{0.0f, 0.0f, 0.0f, 0.0f};
+  float4 ca, cb, na, nb;
+  ca = *reinterpret_cast<const float4*>(ib + fin_off[0]);
+  cb = *reinterpret_cast<const float4*>(ib + fin_off[0] + 64);
+  __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+  for (int tap = 0; tap < kKW; ++tap) {
+    na = ca; nb = cb;
+    if (tap + 1 < kKW) {
+      na = *reinterpret_cast<const float4*>(ib + fin_off[tap + 1]);
+      nb = *reinterpret_cast<const float4*>(ib + fin_off[tap + 1] + 64);
+    }
+    acc = DDD_MFMA16(w[8 * tap + 0], ca.x, acc);
+    acc = DDD_MFMA16(w[8 * tap + 1], ca.y, acc);
+    acc = DDD_MFMA16(w[8 * tap + 2], ca.z, acc);
+    acc = DDD_MFMA16(w[8 * tap + 3], ca.w, acc);
+    acc = DDD_MFMA16(w[8 * tap + 4], cb.x, acc);
+    acc = DDD_MFMA16(w[8 * tap + 5], cb.y, acc);
+    acc = DDD_MFMA16(w[8 * tap + 6], cb.z, acc);
+    acc = DDD_MFMA16(w[8 * tap + 7], cb.w, acc);
+    ca = na; cb = nb;
+    if (tap + 1 < kKW) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+  }
+  return DDD_MFMA16(w[40], 1.0f, acc);   // bias row: k = 160 against a constant 1
 }
 
 // ---------------------------------------------------------------------------
@@ -1123,6 +1304,10 @@ struct Resident {
   float4 hw[kResidentQuads];   // streamed towers: leading weight groups [group][block] of hidden layer 0
   float hwb[2];                // ... and its bias rows (resident_groups)
   bool hw_valid = false;       // (a compile-time constant after inlining: set by setup_weights)
+  // four wavefronts per group (kWR = 16): A operands and LDS byte offsets of the 16x16x4 layers
+  float q_in[kQuadInSteps], q_hid[kQuadHidSteps], q_fin[kQuadFinSteps];
+  int q_in_off[2][2], q_hid_off[2][kKW], q_fin_off[kKW], q_st_off[2];
+  int q_xch_off;            // byte offset (row, channel 4 (l >> 4)) of this lane's output-layer results
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
   float frc_mask[8];        // 1 where entry i of this lane's first 8-mode trip belongs to its run
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
@@ -1273,7 +1458,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // in the free activation buffer.  Every accumulation chain keeps its order: the
   // bits equal the one-wavefront kernel's.
   constexpr bool kSplit = kSpec && kRows == 64 && kWR == 32 && kHoist;
-  constexpr bool kKeepOffsets = (kWR == 64 || kSplit) && kHoist;
+  // kQuad (per-equation integrators, <64, 16>): the same sample on FOUR wavefronts, every
+  // layer on v_mfma_f32_16x16x4_f32 (input_layer_quad .. final_layer_quad above)
+  constexpr bool kQuad = kSpec && kRows == 64 && kWR == 16 && kHoist;
+  static_assert(kWR != 16 || kQuad, "16-row wavefronts: per-equation integrators only");
+  constexpr bool kKeepOffsets = (kWR == 64 || kSplit || kQuad) && kHoist;
   constexpr bool kKeepRows = kKeepOffsets && kEq >= 0 && kLean != 1;
   constexpr bool kKeepPatch = kKeepOffsets && !kWide;   // Resident::pch_idx holds 8 columns
   const int tid = opaque(group_tid<kRows, kWR>());
@@ -1310,7 +1499,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   // conv-tap source rows of this wave's two 32-row tiles (input + hidden
   // layers): index math placed here, in the shadow of the LDS round trip below
   int hid_rows[2][TW::kK];
-  if (!fixed) {
+  if (!fixed && !kQuad) {
     if constexpr (!TW::kDefault) {
 #pragma unroll
       for (int t2 = 0; t2 < 2; ++t2)
@@ -1384,7 +1573,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     // A/B (DDD_PRIO_PHASES): the matrix phases of an evaluation at raised issue priority, the
     // VALU phases (epilogue, forcing, Runge-Kutta update) at the lowest
     if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(3);
-    if constexpr (!TW::kDefault) {
+    if constexpr (kQuad) {
+      input_layer_quad(sm.un, sm.hA, res.q_in, res.q_in_off, res.q_st_off, act, ln.lane);
+    } else if constexpr (!TW::kDefault) {
       input_layer_big<TW, kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, hid_rows, act);
     } else if (!(ablate & 16)) {
       input_layer<kWR, kOneWave, kKeepOffsets>(p, ln, sm.un, un_reg, sm.hA, res.w_in, hid_rows,
@@ -1395,7 +1586,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     float* in = sm.hA;
     float* out = Shared<kRows, kWR, kWide, TW>::kSingleBuffer ? sm.hA : sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
-      if constexpr (!TW::kDefault) {
+      if constexpr (kQuad) {
+        group_barrier<kRows, kWR>();
+        hidden_layer_quad(in, out, res.q_hid, res.q_hid_off, res.q_st_off, act);
+      } else if constexpr (!TW::kDefault) {
         group_barrier<kRows, kWR>();
         if constexpr (TW::kRolled)
           hidden_layer_rolled<TW, kWR>(p, ln, l - 1, in, out, p.N, pow2, act);
@@ -1416,7 +1610,25 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // output layer: weights resident (specialised one-wave integrators) or
       // fetched from L2 here, in flight across the forcing sums below
       // (run-time kernels: the first chunk, up to three groups)
-      if constexpr (kSplit) {
+      if constexpr (kQuad) {
+        constexpr bool kMaskedSums = spec_folded(kSpec ? kEq : 0);
+        if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
+        group_barrier<kRows, kWR>();   // every tile of the last hidden layer is in LDS
+        // this wavefront's own 16 rows, all channels: D[channel 4 (l >> 4) + r][row l & 15]
+        const f32x4 d4 = final_layer_quad(in, res.q_fin, res.q_fin_off);
+        // back to lane == row through the free activation buffer (last read by the hidden
+        // layer: every wavefront has passed the barrier above): rows of this wavefront only,
+        // so waiting for its own stores to land is all the synchronisation there is
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + res.q_xch_off) =
+            make_float4(d4[0], d4[1], d4[2], d4[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const float* mine = out + ln.row * kHS;   // natural channel order here
+#pragma unroll
+        for (int g4 = 0; g4 < kNG; ++g4) {
+          const float4 v = *reinterpret_cast<const float4*>(mine + 4 * g4);
+          net[4 * g4] = v.x; net[4 * g4 + 1] = v.y; net[4 * g4 + 2] = v.z; net[4 * g4 + 3] = v.w;
+        }
+      } else if constexpr (kSplit) {
         constexpr int kNA = (kNG + 1) / 2, kNB = kNG - kNA;   // channel groups of wavefront 0 / 1
         constexpr bool kMaskedSums = spec_folded(kSpec ? kEq : 0);
         if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
@@ -1907,6 +2119,30 @@ __device__ __forceinline__ int forcing_batches(const DevParams& p) {
 template <int kRows, int kWR>
 __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln, Resident& res) {
   int rows[kKW];
+  if constexpr (kWR == 16) {
+    // four wavefronts per group: tiles of 16 positions, reduction slot sg = lane >> 4
+    const int sg = ln.lane >> 4, j16 = ln.lane & 15;
+    const int ph = ln.wave & 1, chh = ln.wave >> 1;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      const int trow = 32 * ph + 16 * t2 + j16;
+      tap_rows<kRows == 64>(ln, trow, p.N, rows);
+#pragma unroll
+      for (int k = 0; k < kKW; ++k)   // block (sg & 1, sg >> 1) of the tap's row
+        res.q_hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
+                                      16 * (4 * (sg & 1) + (sg >> 1)));
+      // input layer: step 0 = tap sg (taps 0..3), step 1 = tap 4 (slot 0)
+      res.q_in_off[t2][0] = opaque(4 * (sg == 0 ? rows[0] : sg == 1 ? rows[1] : sg == 2 ? rows[2] : rows[3]));
+      res.q_in_off[t2][1] = opaque(4 * rows[4]);
+      // D of the tile: channels 16 chh + 4 sg + r -> block (chh, r), element sg
+      res.q_st_off[t2] = opaque((int)__umul24((unsigned)trow, (unsigned)(kHS * 4)) + 64 * chh + 4 * sg);
+    }
+    tap_rows<kRows == 64>(ln, ln.row, p.N, rows);   // the output layer: this wavefront's own rows
+#pragma unroll
+    for (int k = 0; k < kKW; ++k)
+      res.q_fin_off[k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) + 16 * sg);
+    res.q_xch_off = opaque((int)__umul24((unsigned)ln.row, (unsigned)(kHS * 4)) + 16 * sg);
+  }
   // (two 32-row wavefronts per sample: the output layer runs lane == row over all 64 rows)
   tap_rows<kRows == 64>(ln, kWR == 32 ? ln.lane : ln.row, p.N, rows);
 #pragma unroll
@@ -1973,6 +2209,22 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
     }
     res.hw_valid = true;
   }
+  if constexpr (kWR == 16) {
+    // four wavefronts per group: the 16x16x4 A operands of this wavefront's channel half
+    // (DevParams::w_quad: [2][2] input rows, [2][41] hidden rows, [41] output rows x 64 lanes)
+    if (!p.fixed && !p.linear_taps && kHoist && p.w_quad != nullptr) {
+      const float* __restrict__ wq = p.w_quad + opaque(ln.lane);
+      const int chh = ln.wave >> 1;
+#pragma unroll
+      for (int s2 = 0; s2 < kQuadInSteps; ++s2) res.q_in[s2] = wq[(chh * kQuadInSteps + s2) * 64];
+#pragma unroll
+      for (int s2 = 0; s2 < kQuadHidSteps; ++s2)
+        res.q_hid[s2] = wq[(2 * kQuadInSteps + chh * kQuadHidSteps + s2) * 64];
+#pragma unroll
+      for (int s2 = 0; s2 < kQuadFinSteps; ++s2)
+        res.q_fin[s2] = wq[(2 * kQuadInSteps + 2 * kQuadHidSteps + s2) * 64];
+    }
+  } else
   if (!p.fixed && !p.linear_taps && TW::kDefault) {   // (other towers stream every layer's weights)
     load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
@@ -2018,7 +2270,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   }
   res.fk_off = opaque(ln.sl * kTrigMax * 4);   // (fixed-stencil models with forcing read it too)
   res.st_off = 0;
-  if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || p.w_final4_split != nullptr))
+  if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || kWR == 16 || p.w_final4_split != nullptr))
     lane_offsets<kRows, kWR>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)

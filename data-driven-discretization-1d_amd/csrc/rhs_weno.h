@@ -83,6 +83,7 @@ struct Lane {
   // the fixed stencils of derivatives 2, 3 re-indexed by OFFSET: cst[d - 2][i] multiplies
   // u[x + i - 4] (zero outside the stencil's G columns: fma(0, u, s) = s)
   float cst[kMaxDerivs - 2][2 * kHalo];
+  bool lo_in, hi_in;   // offsets -4 / +3 belong to the (common, zero-padded) stencil
 };
 
 template <int kP>
@@ -104,6 +105,8 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, WaveShared& ws, lo
   ln.has_mode = ln.has_sum = false;
   ln.sum_first = ln.sum_cnt = 0;
   const int gl0 = p.G >> 1;                      // patches[i] = u[(x + i - G/2) mod N]
+  ln.lo_in = gl0 >= kHalo;                       // g = -4 + gl0 >= 0
+  ln.hi_in = kHalo - 1 + gl0 < p.G;              // g = +3 + gl0 < G
 #pragma unroll
   for (int d = 0; d < kMaxDerivs - 2; ++d)
 #pragma unroll
@@ -229,10 +232,18 @@ __device__ __forceinline__ void eval(const DevParams& p, Shared& sm, WaveShared&
     minus_plus6(w6, &dv[0], &dv[1]);
 #pragma unroll
     for (int d = 2; d < kD; ++d) {
-      // one chain in stencil order (rhs_generic.h); offsets outside the stencil carry a 0
+      // one chain in stencil order (rhs_generic.h); offsets outside the stencil carry a 0.
+      // Offsets -3 .. +2 lie inside the WENO window (a NaN there marks this point in the
+      // reference too); -4 and +3 may lie outside every stencil: they then read the point
+      // itself, so that 0 x NaN never marks a point the reference does not
       float s = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 2 * kHalo; ++i) s = fmaf(ln.cst[d - 2][i], w[j + i], s);
+      for (int i = 0; i < 2 * kHalo; ++i) {
+        float wv = w[j + i];
+        if (i == 0) wv = ln.lo_in ? wv : w[j + kHalo];
+        if (i == 2 * kHalo - 1) wv = ln.hi_in ? wv : w[j + kHalo];
+        s = fmaf(ln.cst[d - 2][i], wv, s);
+      }
       dv[d] = s;
     }
     if (derivs_out != nullptr) {

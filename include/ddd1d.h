@@ -109,7 +109,10 @@ typedef enum ddd_kernel_kind {
   DDD_KERNEL_MFMA = 2,    /* f32 MFMA tiles; 64 or 256 grid points / block    */
   DDD_KERNEL_MFMA_ROWS64 = 3,  /* force one-wavefront workgroups (N divides 64) */
   DDD_KERNEL_MFMA_ROWS256 = 4, /* force four-wavefront workgroups               */
-  DDD_KERNEL_MFMA_ROWS64_W32 = 5 /* force 64-row groups on two 32-row wavefronts */
+  DDD_KERNEL_MFMA_ROWS64_W32 = 5, /* force 64-row groups on two 32-row wavefronts */
+  DDD_KERNEL_MFMA_ROWS64_W16 = 6  /* force 64-row groups on FOUR 16-row wavefronts
+                                     (small ensembles: one sample on the four SIMDs of
+                                     a CU; per-equation float32 integrators only)      */
 } ddd_kernel_kind;
 
 /* How ddd_integrate_fixed advances time. */

@@ -15,7 +15,7 @@ SCHEMES = {'euler': oracle.SCHEME_EULER, 'midpoint': oracle.SCHEME_MIDPOINT,
 
 
 @pytest.mark.parametrize('scheme', ['euler', 'midpoint', 'bs3', 'rk4'])
-@pytest.mark.parametrize('kernel', ['mfma64', 'mfma64w32', 'mfma256', 'generic'])
+@pytest.mark.parametrize('kernel', ['mfma64', 'mfma64w32', 'mfma64w16', 'mfma256', 'generic'])
 def test_fixed_step_schemes_vs_oracle(scheme, kernel):
   model = make_model('burgers', True, num_points=64, resample_factor=8)
   model.set_kernel(kernel)
@@ -268,12 +268,14 @@ def test_fixed_stencil_streaming_kernels_agree(cls_name, n):
 @pytest.mark.parametrize('equation,conservative,num_points', [
     ('burgers', True, 64), ('burgers', False, 32), ('kdv', True, 64), ('ks', False, 16)])
 def test_small_ensembles_run_two_wavefronts_per_sample(equation, conservative, num_points):
-  """Ensembles that leave every SIMD at most one 64-row wavefront (B <= 1024 at N = 64) run
-  the per-equation integrators with each 64-row group on TWO 32-row wavefronts, the output
-  layer's channel groups divided between them (rhs_mfma.h kSplit).  Every accumulation chain
-  keeps its order, so a sample's bits do not depend on the ensemble around it: equal to
-  the one-wavefront kernel (large ensemble, and the forced mfma64 geometry) and to one
-  launch per substep."""
+  """Small ensembles spread each 64-row group over several wavefronts so that the SIMDs do
+  not idle (the reference's callers integrate tens to hundreds of samples,
+  scripts/run_evaluation.py:212-221): FOUR 16-row wavefronts with every layer on 16x16x4
+  MFMAs (rhs_mfma.h kQuad; the automatic choice while that leaves at most two wavefronts per
+  SIMD) or TWO 32-row wavefronts with the output layer's channel groups divided between
+  them (kSplit).  Every accumulation chain keeps its order, so a sample's bits do not depend
+  on the ensemble around it: equal to the one-wavefront kernel (large ensemble, and the
+  forced mfma64 geometry) and to one launch per substep."""
   model = make_model(equation, conservative, num_points=num_points, resample_factor=2)
   big, small = 1500 * (64 // num_points), 37
   forcing = batch_forcing(big) if equation == 'burgers' else None
@@ -286,15 +288,49 @@ def test_small_ensembles_run_two_wavefronts_per_sample(equation, conservative, n
   if forcing is not None:
     model.set_forcing({k: v[:small] for k, v in forcing.items()})
   b = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
-  assert model.kernel_name == 'mfma_f32_r64w32'
+  assert model.kernel_name == 'mfma_f32_r64w16'
   np.testing.assert_array_equal(a[:, :small], b)
   c = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6,
                             launch_mode='per_substep').cpu().numpy()
   np.testing.assert_array_equal(b, c)
-  model.set_kernel('mfma64')
-  d = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
-  assert model.kernel_name == 'mfma_f32_r64'
-  np.testing.assert_array_equal(b, d)
+  for kernel, name in (('mfma64', 'mfma_f32_r64'), ('mfma64w32', 'mfma_f32_r64w32'),
+                       ('mfma64w16', 'mfma_f32_r64w16')):
+    model.set_kernel(kernel)
+    d = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6).cpu().numpy()
+    assert model.kernel_name == name
+    np.testing.assert_array_equal(b, d)
+  # float64 state has no such kernels: the one-wavefront geometry, silently
+  e = model.integrate_fixed(y0[:small], 12, dt=dt, scheme='bs3', save_every=6,
+                            state_dtype='float64').cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64' and rel_err(e, b) < 1e-6
+
+
+def test_four_wavefronts_per_sample_long_run_and_all_equations():
+  """The kQuad integrators over a longer horizon, all six per-equation kernels, forced and
+  unforced, N = 64 / 32 / 16 / 8 (8, 4, 2, 1 samples per group): bit-equal to the
+  one-wavefront kernel, snapshots included."""
+  for equation, conservative, n in (('burgers', True, 64), ('burgers', False, 64), ('kdv', False, 32),
+                                    ('kdv', True, 8), ('ks', False, 64), ('ks', True, 16)):
+    model = make_model(equation, conservative, num_points=n, resample_factor=2)
+    batch = 19
+    forcing = batch_forcing(batch, seed0=7) if equation == 'burgers' else None
+    model.set_forcing(forcing)
+    y0 = random_phase_ic(model.equation, batch)
+    dt = model.equation.time_step
+    out = {}
+    for kernel in ('mfma64', 'mfma64w16'):
+      model.set_kernel(kernel)
+      out[kernel] = model.integrate_fixed(y0, 100, dt=dt, scheme='midpoint', save_every=25).cpu().numpy()
+    assert model.kernel_name == 'mfma_f32_r64w16'
+    assert np.isfinite(out['mfma64']).all()
+    np.testing.assert_array_equal(out['mfma64'], out['mfma64w16'])
+    want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, 100, 25, y0,
+                                  forcing=forcing)
+    assert rel_err(out['mfma64w16'][:2], want[:2]) < (TOL if equation != 'ks' else 1e-3)
+  # nets without such kernels refuse the explicit choice
+  other = make_model('burgers', True, num_points=64, num_layers=4)
+  with pytest.raises(Exception, match='four 16-row wavefronts'):
+    other.set_kernel('mfma64w16')
 
 
 def test_float64_state():
