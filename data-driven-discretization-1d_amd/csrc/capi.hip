@@ -939,7 +939,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     return DDD_OK;
   }
   m->last_launch_streamed = false; m->last_launch_lean = false;
-  m->last_launch_split = false;
+  m->last_launch_split = false; m->last_launch_quad = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
     ddd::DevParams dp = m->dp;
@@ -2127,7 +2127,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   a.max_attempts = max_attempts;
   m->last_batch = batch;
   m->last_launch_streamed = false; m->last_launch_lean = false;
-  m->last_launch_split = false;
+  m->last_launch_split = false; m->last_launch_quad = false;
   if (m->spectral) {
     // float64 right-hand side (SpectralDifferentiator), one workgroup per sample
     const size_t lds = ddd::spectral::lds_bytes(m->sp);
@@ -2167,9 +2167,31 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   }
   m->dp.dpp_rol = dpp_wave_rol_ok();
   MfmaGeometry geo = mfma_geometry(m, batch);
+  const bool want_quad = geo.rows == 64 && (geo.wave_rows == 16 || (geo.wave_rows == 64 && m->force_rows == 0));
   if (geo.wave_rows != 64) geo = {64, 64};   // the two-wave split has no adaptive instantiation
   const int spg = geo.rows / m->dp.N;
   const int blocks = (batch + spg - 1) / spg;
+  // small ensembles: every 64-row group on four 16-row wavefronts (rhs_mfma.h kQuad), as
+  // launch_integrate chooses it for the fixed-step integrators -- the reference's callers
+  // integrate tens to hundreds of samples (scripts/run_evaluation.py:212-221)
+  m->last_launch_quad = false;
+  if (want_quad && m->dp.w_quad != nullptr && spec_equation(m, 64) >= 0 &&
+      (m->force_rows == 16 || (m->split_auto && !m->explicit_kernel && 2 * blocks <= device_simds()))) {
+    m->last_launch_quad = true;
+    switch (spec_equation(m, 64)) {
+#define DDD_ADAPTIVE_QUAD(EQ) \
+      case EQ: ddd::launch::adaptive_quad_spec<EQ>(m->dp, a, blocks, stream); break;
+      DDD_ADAPTIVE_QUAD(ddd::EQ_BURGERS)
+      DDD_ADAPTIVE_QUAD(ddd::EQ_BURGERS_CONS)
+      DDD_ADAPTIVE_QUAD(ddd::EQ_KDV)
+      DDD_ADAPTIVE_QUAD(ddd::EQ_KDV_CONS)
+      DDD_ADAPTIVE_QUAD(ddd::EQ_KS)
+      DDD_ADAPTIVE_QUAD(ddd::EQ_KS_CONS)
+#undef DDD_ADAPTIVE_QUAD
+      default: break;
+    }
+    return enqueued();
+  }
   switch (spec_equation(m, geo.rows)) {
 #define DDD_ADAPTIVE_CASE(EQ) \
     case EQ: ddd::launch::adaptive_spec<EQ>(geo.rows, m->dp, a, blocks, stream); break;

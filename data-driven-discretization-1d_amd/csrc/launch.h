@@ -29,6 +29,9 @@ void integrate_split_spec(const DevParams& p, const IntegrateArgs& a, int blocks
 template <int kEq>
 void integrate_quad_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
                          hipStream_t stream);
+// ... and the adaptive RK23 on the same four-wavefront groups
+template <int kEq>
+void adaptive_quad_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
 // grid: workgroups to launch (<= groups); every workgroup walks over groups.
 template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
@@ -52,7 +55,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
                                      hipStream_t);                                             \
   template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
   template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
-  template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t);
+  template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
+  template <> void adaptive_quad_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);
 DDD_DECLARE_SPEC(0) DDD_DECLARE_SPEC(1) DDD_DECLARE_SPEC(2)
 DDD_DECLARE_SPEC(3) DDD_DECLARE_SPEC(4) DDD_DECLARE_SPEC(5)
 #undef DDD_DECLARE_SPEC

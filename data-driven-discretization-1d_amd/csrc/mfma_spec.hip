@@ -54,6 +54,13 @@ void integrate_quad_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int
 }
 
 template <>
+void adaptive_quad_spec<DDD_EQ>(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::adaptive_kernel<64, 16, true, DDD_EQ>), dim3(blocks), dim3(256), 0,
+                     stream, p, a);
+}
+
+template <>
 void substep_spec<DDD_EQ>(int rows, const DevParams& p, const SubstepArgs& a, int groups,
                           int grid, hipStream_t stream) {
   if (rows == 64)

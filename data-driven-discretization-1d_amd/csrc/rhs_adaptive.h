@@ -60,6 +60,30 @@ __device__ __forceinline__ double sample_sum(const DevParams& p, const Lane& ln,
   // four-wave groups: `red` aliases Shared::un + Shared::flux (free between two
   // evaluations) -- slower wavefronts may still be reading the flux exchange
   __syncthreads();
+  if constexpr (kWR == 16) {
+    // four 16-row wavefronts per 64-row group (kQuad; N | 64, every 16-lane quarter of a
+    // wavefront carries the same 16 rows): xor butterfly over the sample's rows inside the
+    // quarter, then the partial sums of the sample's wavefronts combined as the
+    // one-wavefront kernel's butterfly combines them -- (w0 + w1) + (w2 + w3) -- so the
+    // controller sees the same bits whatever the geometry
+    const int lane4 = ln.lane << 2;
+    const int inner = p.N < 16 ? p.N : 16;
+    for (int m = 1; m < inner; m <<= 1) {
+      const int src = lane4 ^ (m << 2);
+      const long long bits = __double_as_longlong(v);
+      const int lo = __builtin_amdgcn_ds_bpermute(src, (int)bits);
+      const int hi = __builtin_amdgcn_ds_bpermute(src, (int)(bits >> 32));
+      v += __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+    }
+    if (p.N <= 16) return v;   // (wave-uniform: whole samples inside the quarter)
+    if (ln.lane == 0) red[ln.wave] = v;
+    __syncthreads();
+    double s;
+    if (p.N == 32) s = red[ln.wave & ~1] + red[ln.wave | 1];
+    else s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+  } else
   if ((p.N & 63) == 0) {
     // a sample is N / 64 whole wavefronts (KS N = 256: all four): xor butterfly
     // inside each wavefront, then the sample's wave totals in a fixed order --

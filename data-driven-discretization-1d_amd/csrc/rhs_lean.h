@@ -114,7 +114,9 @@ __global__ __launch_bounds__(64, (waves_per_simd(kK, kD, kGP))) void integrate_k
   for (int d = 0; d < kD; ++d)
 #pragma unroll
     for (int q = 0; q < kGP; ++q) {
-      bias2[d][q] = f32x2{vreg(p.bias8[d][2 * q]), vreg(p.bias8[d][2 * q + 1])};
+      // (the D x G bias stays in SGPRs -- one scalar pair operand of the v_pk_add below --:
+      // twelve VGPRs the 5-tap x 2-derivative instantiation needs to stay spill-free at 128)
+      bias2[d][q] = f32x2{p.bias8[d][2 * q], p.bias8[d][2 * q + 1]};
 #pragma unroll
       for (int k = 0; k < kK; ++k)
         m2[k][d][q] = f32x2{vreg(p.ns8[k * kD + d][2 * q]), vreg(p.ns8[k * kD + d][2 * q + 1])};

@@ -1573,6 +1573,13 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     // A/B (DDD_PRIO_PHASES): the matrix phases of an evaluation at raised issue priority, the
     // VALU phases (epilogue, forcing, Runge-Kutta update) at the lowest
     if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(3);
+    // kernels that do not keep the hidden layer resident (four-wave adaptive integrators,
+    // run-time kernels): the first hidden layer's 81 operand rows are REQUESTED here, before
+    // the input layer, its store and the barrier -- one L2 round trip per evaluation that
+    // used to start right in front of the layer's first MFMA
+    if constexpr (TW::kDefault && !kQuad) {
+      if (!kHoist && nL > 2) load_hidden(p, 0, ln.lane, res.hid);
+    }
     if constexpr (kQuad) {
       input_layer_quad(sm.un, sm.hA, res.q_in, res.q_in_off, res.q_st_off, act, ln.lane);
     } else if constexpr (!TW::kDefault) {
@@ -1599,7 +1606,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
         else
           hidden_layer_stream<TW, kWR>(p, ln, l - 1, in, out, hid_rows, act);
       } else {
-        if (!kHoist) load_hidden(p, l - 1, ln.lane, res.hid);
+        if (!kHoist && l > 1) load_hidden(p, l - 1, ln.lane, res.hid);   // (layer 1: requested above)
         group_barrier<kRows, kWR>();
         hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
       }

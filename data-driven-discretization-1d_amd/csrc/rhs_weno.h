@@ -136,28 +136,43 @@ __device__ __forceinline__ Lane make_lane(const DevParams& p, WaveShared& ws, lo
   return ln;
 }
 
+// x / 3 and x / 6 as the reference's float32 division gives them (correctly rounded) in three
+// FMA-class instructions instead of the ~10 of the IEEE sequence: q = RN(x r), r = RN(1 / d),
+// one Newton step on the exact residual.  Checked exhaustively against x / d over all 2^23
+// significands (the identity is invariant under scaling x by powers of two): 0 mismatches
+// for d = 3 and d = 6.  (Inf becomes NaN, a subnormal quotient may differ in its last bit:
+// neither occurs for the weights, which lie in [0, 1].)  Ten of the 22 divisions per point.
+__device__ __forceinline__ float div3(float x) {
+  const float r = (float)(1.0 / 3.0), q = x * r;
+  return fmaf(fmaf(-q, 3.0f, x), r, q);
+}
+__device__ __forceinline__ float div6(float x) {
+  const float r = (float)(1.0 / 6.0), q = x * r;
+  return fmaf(fmaf(-q, 6.0f, x), r, q);
+}
+
 // weno_minus_plus of dev_params.h on a register window w[0..5] = u[pos - 3 .. pos + 2].
 __device__ __forceinline__ void minus_plus6(const float (&w)[6], float* um, float* up) {
   float is[3], om[3];
   weno_indicators(w[0], w[1], w[2], w[3], w[4], is);
   weno_omega(is, 0.1f, 0.6f, 0.3f, om);
   {
-    const float c0 = om[0] / 3.0f;
-    const float c1 = -(7.0f * om[0] + om[1]) / 6.0f;
-    const float c2 = ((11.0f * om[0] + 5.0f * om[1]) + 2.0f * om[2]) / 6.0f;
-    const float c3 = (2.0f * om[1] + 5.0f * om[2]) / 6.0f;
-    const float c4 = -om[2] / 6.0f;
+    const float c0 = div3(om[0]);
+    const float c1 = div6(-(7.0f * om[0] + om[1]));
+    const float c2 = div6((11.0f * om[0] + 5.0f * om[1]) + 2.0f * om[2]);
+    const float c3 = div6(2.0f * om[1] + 5.0f * om[2]);
+    const float c4 = div6(-om[2]);
     *um = (((c0 * w[0] + c1 * w[1]) + c2 * w[2]) + c3 * w[3]) + c4 * w[4];
   }
   weno_indicators(w[1], w[2], w[3], w[4], w[5], is);
   weno_omega(is, 0.3f, 0.6f, 0.1f, om);
   {
     const float o2 = om[0], o1 = om[1], o0 = om[2];
-    const float c0 = -o2 / 6.0f;
-    const float c1 = (5.0f * o2 + 2.0f * o1) / 6.0f;
-    const float c2 = ((2.0f * o2 + 5.0f * o1) + 11.0f * o0) / 6.0f;
-    const float c3 = -(o1 + 7.0f * o0) / 6.0f;
-    const float c4 = o0 / 3.0f;
+    const float c0 = div6(-o2);
+    const float c1 = div6(5.0f * o2 + 2.0f * o1);
+    const float c2 = div6((2.0f * o2 + 5.0f * o1) + 11.0f * o0);
+    const float c3 = div6(-(o1 + 7.0f * o0));
+    const float c4 = div3(o0);
     *up = (((c0 * w[1] + c1 * w[2]) + c2 * w[3]) + c3 * w[4]) + c4 * w[5];
   }
 }

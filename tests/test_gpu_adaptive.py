@@ -146,7 +146,7 @@ def test_reference_settings_n64(equation, conservative):
   one launch, each with its own controller, forcing and nfev."""
   batch = 64
   model = make_model(equation, conservative, num_points=64, resample_factor=4)
-  assert model.kernel_name == 'mfma_f32_r64'
+  assert model.kernel_name == 'mfma_f32_r64'   # (before any launch; 64 samples run four wavefronts each)
   scale = 0.3 if equation == 'burgers' else 1.0
   y0 = (scale * random_phase_ic(model.equation, batch)).astype(np.float64)
   forcing = batch_forcing(batch) if equation == 'burgers' else None
@@ -361,3 +361,34 @@ def test_other_towers_adaptive(overrides):
     print(overrides, num_points, 'nfev', nfev, 'worst {:.1e}'.format(worst))
     assert not bad, bad
     assert (status == 0).all()
+
+
+@pytest.mark.parametrize('equation,conservative,num_points,max_step', [
+    ('burgers', True, 64, 0.01), ('burgers', False, 32, np.inf), ('kdv', True, 64, 0.01),
+    ('ks', False, 16, np.inf), ('kdv', False, 8, np.inf)])
+def test_small_ensembles_on_four_wavefronts_per_group(equation, conservative, num_points, max_step):
+  """ddd_integrate_adaptive_f64 for a small ensemble runs every 64-row group on FOUR 16-row
+  wavefronts (rhs_mfma.h kQuad, chosen automatically while that leaves at most two wavefronts
+  per SIMD).  Right-hand side and error norm keep the one-wavefront kernel's operation order,
+  so evaluation counts, status and trajectories are EQUAL to the forced one-wavefront
+  geometry, bit for bit -- a sample's result does not depend on the ensemble around it."""
+  batch = 23
+  model = make_model(equation, conservative, num_points=num_points, resample_factor=4)
+  scale = 0.4 if equation == 'burgers' else 1.0
+  y0 = (scale * random_phase_ic(model.equation, batch)).astype(np.float64)
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  model.set_forcing(forcing)
+  times = np.array([0.0, 0.013, 0.1, 0.2])
+  y, nfev, status = model.integrate_adaptive(y0, times, max_step=max_step)
+  assert model.kernel_name == 'mfma_f32_r64w16'
+  model.set_kernel('mfma64')
+  y1, nfev1, status1 = model.integrate_adaptive(y0, times, max_step=max_step)
+  assert model.kernel_name == 'mfma_f32_r64'
+  np.testing.assert_array_equal(nfev.cpu().numpy(), nfev1.cpu().numpy())
+  np.testing.assert_array_equal(status.cpu().numpy(), status1.cpu().numpy())
+  np.testing.assert_array_equal(y.cpu().numpy(), y1.cpu().numpy())
+  assert (status.cpu().numpy() == 0).all() and len(np.unique(nfev.cpu().numpy())) >= 1
+  model.set_kernel('mfma64w16')
+  y2, nfev2, _ = model.integrate_adaptive(y0, times, max_step=max_step)
+  assert model.kernel_name == 'mfma_f32_r64w16'
+  np.testing.assert_array_equal(y.cpu().numpy(), y2.cpu().numpy())
