@@ -1014,7 +1014,7 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   // per-equation instantiations exist for 64-row wavefronts: float32 state in
   // both geometries, float64 state -- the SciPy-driven reference semantics,
   // integrate.py:154 -- in the one-wave geometry (launch.h)
-  int eq = (kWR == 64 && (!f64 || kRows == 64)) ? spec_equation(m, kRows) : -1;
+  int eq = kWR == 64 ? spec_equation(m, kRows) : -1;   // (float64 state: both geometries since round 6)
   if (kWR == 32 && !f64 && m->dp.w_final4_split != nullptr) eq = spec_equation(m, kRows);
   if (kWR == 16) eq = (!f64 && m->dp.w_quad != nullptr) ? spec_equation(m, kRows) : -1;
   bool traced = false;

@@ -33,6 +33,12 @@ void integrate_spec<DDD_EQ>(int rows, bool f64, bool traced, const DevParams& p,
     (void)traced;
     hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ>), grid, dim3(64), 0,
                        stream, p, a);
+  } else if (f64) {
+    // float64 state on four-wave groups (SciPy holds y in float64, integrate.py:154): round 6 --
+    // these ran on the run-time kernel at 70.8 % where the float32 state runs at 83 %
+    // (profiles/r6_adaptive_gap.txt)
+    hipLaunchKernelGGL((mfma::integrate_kernel<256, 64, double, true, DDD_EQ>), grid, dim3(256),
+                       0, stream, p, a);
   } else {
     hipLaunchKernelGGL((mfma::integrate_kernel<256, 64, float, true, DDD_EQ>), grid, dim3(256),
                        0, stream, p, a);
@@ -82,6 +88,15 @@ void step_spec<DDD_EQ>(int rows, const DevParams& p, const StepArgs& a, int grou
                        stream, p, a, groups);
 }
 
+// The four-wave adaptive kernels keep the whole tower resident (kHoist) where that fits 256
+// VGPRs without a spill -- KdV and KS: 255 registers, 0 scratch, two workgroups per CU --;
+// the Burgers kernels (forcing state on top: 21-28 spills when hoisted) fetch the hidden
+// layer's operands per evaluation as before.  profiles/r6_adaptive_gap.txt: with the weights
+// streamed, KS N = 256 ran at the rate of the float64-state run-time kernel (70.8 %), 12
+// points below the resident fixed-step kernel.
+#ifndef DDD_ADAPT256_HOIST
+#define DDD_ADAPT256_HOIST (DDD_EQ >= 2)
+#endif
 template <>
 void adaptive_spec<DDD_EQ>(int rows, const DevParams& p, const AdaptiveArgs& a, int blocks,
                            hipStream_t stream) {
@@ -89,7 +104,7 @@ void adaptive_spec<DDD_EQ>(int rows, const DevParams& p, const AdaptiveArgs& a, 
     hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ>), dim3(blocks), dim3(64), 0,
                        stream, p, a);
   else
-    hipLaunchKernelGGL((mfma::adaptive_kernel<256, 64, false, DDD_EQ>), dim3(blocks), dim3(256),
+    hipLaunchKernelGGL((mfma::adaptive_kernel<256, 64, DDD_ADAPT256_HOIST, DDD_EQ>), dim3(blocks), dim3(256),
                        0, stream, p, a);
 }
 

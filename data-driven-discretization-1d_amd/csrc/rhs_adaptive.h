@@ -29,6 +29,12 @@
 #pragma once
 #include "rhs_mfma.h"
 #include "rk23.h"
+#ifdef DDD_PROBES   // libddd1d_probe.so: phase stamps (profiles/tools/adaptive_phase_trace.py)
+#include "rhs_adaptive_trace.h"
+#else
+#define DDD_ADAPT_TRACE_SETUP do {} while (0)
+#define DDD_ADAPT_STAMP(K) do {} while (0)
+#endif
 
 namespace ddd {
 namespace mfma {
@@ -237,7 +243,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
   int phase = 0;
   int round = 0;
   bool sums_ready = false;   // res.fk_next already holds the forcing sums of this evaluation
+  DDD_ADAPT_TRACE_SETUP;
   for (;;) {
+    DDD_ADAPT_STAMP(0);
     double tt, yy, tt_next;
     {
       const double ct = ctl[slot].t, ch = ctl[slot].h;   // (phase 1: h = h0)
@@ -275,9 +283,11 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
         res.fk_next = forcing_sums<kRows, kWR, kMaskedSums>(p, sm, res, (float)ft_now, tid);
       tn_lane = (float)ft_next;
     }
+    DDD_ADAPT_STAMP(1);
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>(), TW>(
         p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
     sums_ready = ahead;
+    DDD_ADAPT_STAMP(2);
     if (DDD_ADAPTIVE_SHORTCUT && (phase == 2 || phase == 3)) {
       // Stages 2 and 3 of an attempt change nothing of the controller but the evaluation
       // count, and no sample can finish here: no controller load / unpack / store, no vote
@@ -298,6 +308,8 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
         phase = 4;
       }
       if (keeper && run) ctl[slot].nfev += 1;   // (the keeper alone touches this field)
+      DDD_ADAPT_STAMP(3);
+      DDD_ADAPT_STAMP(4);
       continue;
     }
     // (eval_rhs's barriers are compiler barriers too: this is a fresh read)
@@ -366,6 +378,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
     // every lane of the sample has read the controller (above); the keeper publishes
     // the new one.  The vote below is the barrier that orders it before the next read.
     const int running = c.status == rk23::RUNNING;
+    DDD_ADAPT_STAMP(3);
     if (kRows != kWR) __syncthreads();   // four-wave groups: all lanes' reads before the write
     if (keeper) {
       ctl[slot].store(c);
@@ -386,6 +399,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
       ++round;
       if (!go) break;
     }
+    DDD_ADAPT_STAMP(4);
   }
 
   const rk23::Control c = ctl[slot].load();

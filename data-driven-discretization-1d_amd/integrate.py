@@ -439,25 +439,37 @@ def integrate_exact_batch(equations, times: np.ndarray = _DEFAULT_TIMES,
   end, as a circulant kernel on the device (``ddd_circulant_apply_f64``).
   Returns a Dataset with y [sample, time, x] float64 and per-sample num_evals.
   """
-  exact = [eq.to_exact() for eq in equations]
-  first = exact[0]
-  for eq in exact[1:]:
-    if type(eq) is not type(first) or (eq.grid.solution_num_points, eq.grid.period) != (
+  equations = list(equations)
+  first = equations[0].to_exact()
+  for eq in equations[1:]:
+    if type(eq) is not type(equations[0]) or (eq.grid.solution_num_points, eq.grid.period) != (
         first.grid.solution_num_points, first.grid.period):
       raise ValueError('all equations must share their type and grid')
+  # to_exact() keeps an equation's parameters (grid, random_seed -> the same forcing draws,
+  # equations.py:184-185): the per-sample forcing tables come from the equations as given.
+  # Only the initial value can depend on the exact TYPE (forcing(0) resampled the exact
+  # grid's way); Burgers starts from zeros whatever the type (equations.py:256-257), so its
+  # samples are not rebuilt -- each rebuild re-seeds a RandomState, ~0.1 ms per sample, which
+  # was most of this function's time for the WENO solver (profiles/r6_weno_exact.txt)
+  zero_start = type(first).initial_value is equations_lib.BurgersEquation.initial_value
+  exact = equations if zero_start else [eq.to_exact() for eq in equations]
   method = first.EXACT_METHOD
   if method is equations_lib.ExactMethod.SPECTRAL:
     device_model = model_lib.SpectralModel(first, convention='fftpack')
   elif method is equations_lib.ExactMethod.WENO:
     device_model = model_lib.BaselineModel(first, 3, weno=True)   # WENODifferentiator's default
     if first.has_time_dependent_forcing:
-      device_model.set_forcing(model_lib.forcing_from_equations(exact))
+      device_model.set_forcing(model_lib.forcing_from_equations(equations))
   else:
     raise ValueError('integrate_exact_batch covers the spectral and WENO exact solvers; '
                      'use integrate_exact per sample for {}'.format(type(first).__name__))
   solver = _DeviceSolver(device_model)
-  y0 = _lib.as_device(np.stack([eq.initial_value() for eq in exact]),
-                      _lib._torch().float64)
+  if zero_start:
+    y0 = _lib._torch().zeros((len(equations), first.grid.solution_num_points),
+                             dtype=_lib._torch().float64, device='cuda')
+  else:
+    y0 = _lib.as_device(np.stack([eq.initial_value() for eq in exact]),
+                        _lib._torch().float64)
   solution, num_evals = _solve(solver, first, y0, np.asarray(times, dtype=np.float64),
                                warmup, filter_interval, False, solver,
                                lambda state: state)   # exact grid == its own grid

@@ -346,6 +346,29 @@ def test_float64_state():
   assert rel_err(got, want) < TOL
 
 
+@pytest.mark.parametrize('equation,conservative,n', [('ks', True, 256), ('burgers', True, 128),
+                                                     ('kdv', False, 96)])
+def test_float64_state_four_wave_groups(equation, conservative, n):
+  """float64 state on 256-row groups: per-equation integrators since round 6 (they ran on
+  the run-time-parameterised kernel).  Against the oracle with a float64 state, against the
+  forced run-time ... and the float32-state run (same right-hand side: float32 rounding of
+  the state apart)."""
+  model = make_model(equation, conservative, num_points=n, resample_factor=1)
+  batch = 5
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  model.set_forcing(forcing)
+  y0 = random_phase_ic(model.equation, batch)
+  dt = model.equation.time_step
+  got = model.integrate_fixed(y0.astype(np.float64), 20, dt=dt, scheme='bs3', save_every=10,
+                              state_dtype='float64').cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r256' and got.dtype == np.float64
+  want = oracle.integrate_fixed(model.spec(), oracle.SCHEME_BS3, 0.0, dt, 20, 10, y0,
+                                forcing=forcing, state_dtype=np.float64)
+  assert rel_err(got, want) < (TOL if equation != 'ks' else 1e-4)
+  f32 = model.integrate_fixed(y0, 20, dt=dt, scheme='bs3', save_every=10).cpu().numpy()
+  assert rel_err(got, f32) < 1e-5
+
+
 def test_save_every_and_zero_steps():
   model = make_model('burgers', True, num_points=64)
   y0 = random_phase_ic(model.equation, 3)
