@@ -443,7 +443,7 @@ def integrate_exact_batch(equations, times: np.ndarray = _DEFAULT_TIMES,
   first = equations[0].to_exact()
   for eq in equations[1:]:
     if type(eq) is not type(equations[0]) or (eq.grid.solution_num_points, eq.grid.period) != (
-        first.grid.solution_num_points, first.grid.period):
+        equations[0].grid.solution_num_points, equations[0].grid.period):
       raise ValueError('all equations must share their type and grid')
   # to_exact() keeps an equation's parameters (grid, random_seed -> the same forcing draws,
   # equations.py:184-185): the per-sample forcing tables come from the equations as given.
