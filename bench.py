@@ -704,17 +704,29 @@ def _external_driver_config(args):
               'frac': flops / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 'jobs': jobs,
               'timed_wall_ms': wall * 1e3, 'finite': bool(torch.isfinite(last).all())}, last
 
+    # the region on launches: two half-ensemble chains (round 4; the default) ...
     c_chained, y_c = timed(c_loop, True)
     y_c = y_c.clone()
     py_chained, y_py = timed(python_loop, True)
     same = bool(torch.equal(y_c, y_py))
     py_plain, y_plain = timed(python_loop, False)
     same = same and bool(torch.equal(y_c, y_plain))
+    # ... and on the command ring (round 6, opt-in: ONE persistent kernel takes the calls as
+    # 128-byte commands; DDD_REGION_RING)
+    model.set_region_mode('ring')
+    before = model.region_stats()
+    c_ring, y_ring = timed(c_loop, True)
+    after = model.region_stats()
+    same = same and bool(torch.equal(y_c, y_ring))
+    model.set_region_mode('auto')
     ref = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
                                 launch_mode='per_substep')[0]
     out['b{}'.format(batch)] = {
         'c_loop_chained': c_chained, 'python_loop_chained': py_chained,
+        'c_loop_command_ring': c_ring,
         'python_loop_unchained': py_plain,
+        'ring': {'persistent_kernel_launches': after[0] - before[0],
+                 'commands': after[1] - before[1]},
         'drivers_bit_identical': same,
         'equals_ddd_integrate_fixed_per_substep': bool(torch.equal(y_c, ref)),
     }
@@ -724,7 +736,9 @@ def _external_driver_config(args):
       'workload': 'headline model (Burgers N=64 conv-net stencils), midpoint, a HOST loop that owns '
                   'the RK stages: 2 ddd_rk_substep calls per step, {} steps per job, batch 4096 '
                   'and 8192 (tiled from 4096 distinct samples); value = the C loop inside '
-                  'ddd_stream_fork .. ddd_stream_join at batch 4096'.format(steps),
+                  'ddd_stream_fork .. ddd_stream_join at batch 4096 (two chains of launches; '
+                  'c_loop_command_ring = the same region on the opt-in device-resident command '
+                  'ring: one persistent kernel, every call a 128-byte command)'.format(steps),
       'value': best['value'], 'unit': 'grid-point-steps/s', 'bound': 'mfma',
       'achieved': best['fp32_tflops'], 'peak': PEAK_FP32_TFLOPS, 'roofline_unit': 'TFLOP/s',
       'frac': best['frac'], 'finite': best['finite'], 'kernel': 'mfma_f32_r64',

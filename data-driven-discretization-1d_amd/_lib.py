@@ -87,6 +87,9 @@ SIGNATURES = {
                                       _V, ctypes.c_int, _V]),
     'ddd_stream_fork': (ctypes.c_int, [_V, _V]),
     'ddd_stream_join': (ctypes.c_int, [_V, _V]),
+    'ddd_set_region_mode': (ctypes.c_int, [_V, ctypes.c_int]),
+    'ddd_region_stats': (ctypes.c_int, [_V, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int64)]),
     'ddd_integrate_fixed': (ctypes.c_int, [_V, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_double,
                                            ctypes.c_int, ctypes.c_int, _V, _V,

@@ -3,13 +3,19 @@
 // boundary.
 #include <hip/hip_runtime.h>
 
+#include <emmintrin.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -26,6 +32,7 @@
 #include "rhs_mfma.h"
 #include "rhs_spectral.h"
 #include "rhs_stream.h"
+#include "ring_args.h"
 #include "rhs_weno.h"   // (host side only: weno::supports; the kernels are weno_unit.hip)
 
 namespace {
@@ -176,6 +183,90 @@ ddd::StageConsts make_stage_consts(const ddd::Tableau& tab, double dt) {
   return sc;
 }
 
+// Host side of the device-resident command ring (dev_params.h: RingArgs; rhs_mfma.h:
+// substep_ring_kernel).  The caller's thread posts commands; a park thread (one per model that
+// ever used the ring) posts kRingStop when the region has been idle for `idle` -- a caller
+// that synchronises the device, or enqueues other work behind the persistent kernel, inside
+// an open region waits that long, not for ever; the next ddd_rk_substep starts the kernel again.
+struct Ring {
+  void* slots = nullptr;         // page-locked, device-visible: [kRingSlots][kRingSlotChunks] x 16 B
+  unsigned* done = nullptr;      // page-locked: [kRingSlots], written by the kernel
+  unsigned* status = nullptr;    // page-locked: [0] watchdog expired
+  unsigned* d_count = nullptr;   // device: [kRingSlots] + the relay lock
+  void* d_slots = nullptr;       // device (fine-grained): the relayed commands
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread parker;
+  bool quit = false;
+  bool running = false;          // a substep_ring_kernel is waiting for commands on `stream`
+  bool dead = false;             // the watchdog expired: results of the region are undefined
+  hipStream_t stream = nullptr;
+  unsigned long long next_index = 0;    // index of the next command
+  unsigned long long launch_index = 0;  // first command of the running kernel
+  int grid = 0;
+  std::chrono::steady_clock::time_point last_post;
+  std::chrono::microseconds idle{2000};
+  unsigned watchdog_ms = 20000;
+  unsigned long long launches = 0, commands = 0;   // statistics (ddd_region_stats)
+};
+
+// One 16-byte store per chunk (see dev_params.h): payload dwords 3 c .. 3 c + 2, then the tag.
+void ring_write(Ring* rg, unsigned long long index, const unsigned (&payload)[3 * ddd::kRingChunks]) {
+  const unsigned tag = (unsigned)(index + 1ull);
+  __m128i* slot = reinterpret_cast<__m128i*>(rg->slots) +
+                  (size_t)(index & (ddd::kRingSlots - 1)) * ddd::kRingSlotChunks;
+  for (int c = 0; c < ddd::kRingChunks; ++c)
+    _mm_store_si128(slot + c, _mm_set_epi32((int)tag, (int)payload[3 * c + 2],
+                                            (int)payload[3 * c + 1], (int)payload[3 * c]));
+}
+
+// Room for command `index`: the command kRingSlots before it has been passed by every group
+// (or belongs to a kernel that has ended).  False: no progress for 10 s.
+bool ring_wait_room(Ring* rg, unsigned long long index) {
+  if (index < (unsigned long long)ddd::kRingSlots) return true;
+  const unsigned long long old = index - ddd::kRingSlots;
+  // (no shortcut for commands of an earlier launch: that kernel may still be working through
+  // them while the next one is already enqueued behind it)
+  const volatile unsigned* flag = rg->done + (old & (ddd::kRingSlots - 1));
+  const unsigned want = (unsigned)(old + 1ull);
+  if (*flag == want) return true;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0; *flag != want; ++spin) {
+    _mm_pause();
+    if ((spin & 0xfff) == 0xfff) {
+      if (*reinterpret_cast<const volatile unsigned*>(rg->status) != 0u) return false;
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) return false;
+    }
+  }
+  return true;
+}
+
+// (rg->mu held)  Ends the running kernel: kRingStop is a command like any other, every group
+// leaves after the commands before it.
+bool ring_stop_locked(Ring* rg) {
+  if (!rg->running) return true;
+  rg->running = false;
+  const bool room = ring_wait_room(rg, rg->next_index);
+  unsigned payload[3 * ddd::kRingChunks] = {};
+  payload[14] = (unsigned)ddd::kRingStop;
+  // (without room the slot is overwritten all the same: the kernel must end, and a region
+  // that made no progress for 10 s is reported as failed)
+  ring_write(rg, rg->next_index, payload);
+  ++rg->next_index;
+  if (!room) rg->dead = true;
+  return room;
+}
+
+void ring_parker(Ring* rg) {
+  std::unique_lock<std::mutex> lk(rg->mu);
+  while (!rg->quit) {
+    if (!rg->running) { rg->cv.wait(lk); continue; }
+    const auto deadline = rg->last_post + rg->idle;
+    if (std::chrono::steady_clock::now() >= deadline) { (void)ring_stop_locked(rg); continue; }
+    rg->cv.wait_until(lk, deadline);
+  }
+}
+
 }  // namespace
 
 struct ddd_model {
@@ -234,6 +325,10 @@ struct ddd_model {
     int batch = 0, halves = 1;
     int half_batch[4] = {0, 0, 0, 0}, slab_first[4] = {0, 0, 0, 0};
   } chain;
+  // ... or, for the per-equation one-wave kernels, ONE persistent kernel fed through a
+  // device-resident command ring (Ring above)
+  Ring* ring = nullptr;
+  int region_mode = DDD_REGION_AUTO;
   // output times of ddd_integrate_adaptive_f64: a small ring of (page-locked host
   // copy, device copy) pairs, each released by an event recorded behind the launch
   // that reads it -- the entry point only enqueues (no host synchronisation unless
@@ -1236,11 +1331,148 @@ int join_lanes(ddd_model* m, hipStream_t stream, int halves) {
 // sees every substep enqueued so far.
 int chain_close(ddd_model* m) {
   int rc = DDD_OK;
+  if (m->ring != nullptr) {
+    std::lock_guard<std::mutex> lk(m->ring->mu);
+    if (!ring_stop_locked(m->ring))
+      rc = fail(DDD_ERR_HIP, "command ring: the persistent kernel made no progress for 10 s");
+  }
   if (m->chain.open && m->chain.forked && m->chain.halves > 1)
     rc = join_lanes(m, m->chain.stream, m->chain.halves);
   m->chain.open = false;
   m->chain.forked = false;
   return rc;
+}
+
+// The region can run on the command ring: a per-equation kernel on one-wave groups (N | 64),
+// the whole ensemble from sample 0, no derivative / coefficient views.
+bool ring_eligible(const ddd_model* m, const ddd::SubstepArgs& a) {
+  if (m->region_mode != DDD_REGION_RING) return false;   // (opt-in: measured equal to the launches)
+  if (m->kernel != DDD_KERNEL_MFMA || m->explicit_kernel || g_debug.no_spec) return false;
+  if (a.batch <= 0 || a.derivs_out != nullptr || a.coeffs_out != nullptr) return false;
+  if (use_stream_kernel(m, a)) return false;
+  MfmaGeometry geo = mfma_geometry(m, a.batch);
+  if (geo.wave_rows == 16) geo = {64, 64};
+  return geo.rows == 64 && geo.wave_rows == 64 && spec_equation(m, 64) >= 0;
+}
+
+int ring_create(ddd_model* m) {
+  Ring* rg = new Ring();
+  const size_t slot_bytes = (size_t)ddd::kRingSlots * ddd::kRingSlotChunks * 16;
+  hipError_t err = hipHostMalloc(&rg->slots, slot_bytes, hipHostMallocCoherent | hipHostMallocMapped);
+  if (err == hipSuccess)
+    err = hipHostMalloc(reinterpret_cast<void**>(&rg->done), (ddd::kRingSlots + 32 + 2048) * sizeof(unsigned),
+                        hipHostMallocCoherent | hipHostMallocMapped);
+  if (err == hipSuccess)
+    err = hipMalloc(reinterpret_cast<void**>(&rg->d_count), (ddd::kRingSlots + 16) * sizeof(unsigned));
+  if (err == hipSuccess)   // fine-grained: every XCD's L2 sees the relaying wavefront's stores
+    err = hipExtMallocWithFlags(&rg->d_slots, slot_bytes, hipDeviceMallocFinegrained);
+  if (err == hipSuccess)   // (every slot's last group resets its count; the relay lock starts open)
+    err = hipMemset(rg->d_count, 0, (ddd::kRingSlots + 16) * sizeof(unsigned));
+  if (err == hipSuccess) err = hipMemset(rg->d_slots, 0, slot_bytes);
+  if (err == hipSuccess) err = hipDeviceSynchronize();
+  if (err != hipSuccess) {
+    if (rg->slots) (void)hipHostFree(rg->slots);
+    if (rg->done) (void)hipHostFree(rg->done);
+    if (rg->d_count) (void)hipFree(rg->d_count);
+    if (rg->d_slots) (void)hipFree(rg->d_slots);
+    delete rg;
+    return fail(DDD_ERR_HIP, "command ring: %s", hipGetErrorString(err));
+  }
+  std::memset(rg->slots, 0, slot_bytes);
+  std::memset(rg->done, 0, (ddd::kRingSlots + 32 + 2048) * sizeof(unsigned));   // (+ status, trace stamps)
+  rg->status = rg->done + ddd::kRingSlots;
+  rg->parker = std::thread(ring_parker, rg);
+  m->ring = rg;
+  return DDD_OK;
+}
+
+void ring_destroy(ddd_model* m) {
+  Ring* rg = m->ring;
+  if (rg == nullptr) return;
+  {
+    std::lock_guard<std::mutex> lk(rg->mu);
+    (void)ring_stop_locked(rg);
+    rg->quit = true;
+  }
+  rg->cv.notify_all();
+  rg->parker.join();
+  if (rg->stream != nullptr) (void)hipStreamSynchronize(rg->stream);   // the kernel reads the ring until it ends
+  (void)hipHostFree(rg->slots);
+  (void)hipHostFree(rg->done);
+  (void)hipFree(rg->d_count);
+  (void)hipFree(rg->d_slots);
+  delete rg;
+  m->ring = nullptr;
+}
+
+// One command = one ddd_rk_substep call.  Starts the persistent kernel when none is waiting.
+int ring_post(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
+  if (m->ring == nullptr) { int rc = ring_create(m); if (rc) return rc; }
+  Ring* rg = m->ring;
+  std::unique_lock<std::mutex> lk(rg->mu);
+  if (rg->dead || *reinterpret_cast<const volatile unsigned*>(rg->status) != 0u) {
+    rg->dead = true; rg->running = false;
+    return fail(DDD_ERR_HIP, "command ring: the persistent kernel gave up waiting (watchdog) or "
+                             "made no progress; the region's results are undefined");
+  }
+  if (rg->running && rg->stream != stream) (void)ring_stop_locked(rg);
+  if (!rg->running) {
+    m->dp.dpp_rol = dpp_wave_rol_ok();
+    const int spg = 64 / m->dp.N;
+    const int groups = (a.batch + spg - 1) / spg;
+    rg->grid = std::min(groups, 2 * device_simds());
+    ddd::RingArgs r{};
+    r.slots = rg->slots; r.dev_slots = rg->d_slots; r.count = rg->d_count; r.done = rg->done; r.status = rg->status;
+    r.first_index = (unsigned)rg->next_index;
+    r.watchdog_ticks = rg->watchdog_ms * 100000u;   // 100 MHz
+    const int eq = spec_equation(m, 64);
+#define DDD_RING_CASE(EQ) \
+    case EQ: ddd::launch::substep_ring_spec<EQ>(m->dp, r, rg->grid, stream); break;
+    switch (eq) {
+      DDD_RING_CASE(ddd::EQ_BURGERS)
+      DDD_RING_CASE(ddd::EQ_BURGERS_CONS)
+      DDD_RING_CASE(ddd::EQ_KDV)
+      DDD_RING_CASE(ddd::EQ_KDV_CONS)
+      DDD_RING_CASE(ddd::EQ_KS)
+      DDD_RING_CASE(ddd::EQ_KS_CONS)
+      default: return fail(DDD_ERR_UNSUPPORTED, "command ring: no per-equation kernel");
+    }
+#undef DDD_RING_CASE
+    DDD_HIP(hipGetLastError());
+    rg->running = true;
+    rg->stream = stream;
+    rg->launch_index = rg->next_index;
+    ++rg->launches;
+    rg->last_post = std::chrono::steady_clock::now();
+    rg->cv.notify_all();
+  }
+  if (!ring_wait_room(rg, rg->next_index)) {
+    rg->dead = true;
+    (void)ring_stop_locked(rg);
+    return fail(DDD_ERR_HIP, "command ring: the persistent kernel made no progress for 10 s");
+  }
+  unsigned payload[3 * ddd::kRingChunks] = {};
+  const auto put64 = [&](int j, unsigned long long v) {
+    payload[j] = (unsigned)v; payload[j + 1] = (unsigned)(v >> 32);
+  };
+  unsigned long long tbits; std::memcpy(&tbits, &a.t, 8);
+  put64(0, tbits);
+  put64(2, (unsigned long long)(uintptr_t)a.y_in);
+  put64(4, (unsigned long long)(uintptr_t)a.y_base);
+  put64(6, (unsigned long long)(uintptr_t)a.y_out);
+  put64(8, (unsigned long long)(uintptr_t)a.acc_in);
+  put64(10, (unsigned long long)(uintptr_t)a.acc_out);
+  std::memcpy(&payload[12], &a.c1, 4);
+  std::memcpy(&payload[13], &a.c2, 4);
+  payload[14] = (unsigned)a.batch;
+  ring_write(rg, rg->next_index, payload);
+  ++rg->next_index;
+  ++rg->commands;
+  rg->last_post = std::chrono::steady_clock::now();
+  m->last_batch = a.batch;
+  m->last_launch_streamed = false; m->last_launch_lean = false;
+  m->last_launch_split = false; m->last_launch_quad = false;
+  return DDD_OK;
 }
 
 // One substep of a caller-owned Runge-Kutta loop.  Outside a chained region: one
@@ -1251,6 +1483,18 @@ int substep_entry(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
   ddd_model::Chain& ch = m->chain;
   if (!ch.open || stream != ch.stream || a.derivs_out != nullptr || a.coeffs_out != nullptr)
     return launch_substep(m, a, stream);
+  if (ring_eligible(m, a)) {
+    if (ch.forked && ch.halves > 1) {   // (a region that started on the two chains)
+      int rc = join_lanes(m, stream, ch.halves);
+      ch.forked = false;
+      if (rc) return rc;
+    }
+    return ring_post(m, a, stream);
+  }
+  if (m->ring != nullptr) {   // this call takes launches: behind every command posted so far
+    std::lock_guard<std::mutex> lk(m->ring->mu);
+    (void)ring_stop_locked(m->ring);
+  }
   if (!ch.forked || ch.batch != a.batch) {
     if (ch.forked && ch.halves > 1) {   // another batch: other slabs, so join first
       int rc = join_lanes(m, stream, ch.halves);
@@ -1634,6 +1878,7 @@ int ddd_rk_substep_f64(ddd_model* m, double t, const double* y_in, const double*
 int ddd_model_destroy(ddd_model* m) {
   if (m == nullptr) return DDD_OK;
   (void)chain_close(m);   // the caller's stream sees every substep before the buffers go
+  ring_destroy(m);
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
@@ -1792,6 +2037,31 @@ int ddd_stream_fork(ddd_model* m, void* stream) {
   if (rc) return rc;
   m->chain.open = true;
   m->chain.stream = static_cast<hipStream_t>(stream);
+  return DDD_OK;
+}
+
+int ddd_set_region_mode(ddd_model* m, int mode) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  if (mode != DDD_REGION_AUTO && mode != DDD_REGION_CHAINS && mode != DDD_REGION_RING)
+    return fail(DDD_ERR_INVALID_ARGUMENT, "unknown region mode %d", mode);
+  int rc = chain_close(m);
+  if (rc) return rc;
+  m->region_mode = mode;
+  return DDD_OK;
+}
+
+int ddd_region_stats(const ddd_model* m, int64_t* ring_launches, int64_t* ring_commands) {
+  if (m == nullptr) return fail(DDD_ERR_INVALID_ARGUMENT, "model is NULL");
+  long long launches = 0, commands = 0;
+  if (m->ring != nullptr) {
+    std::lock_guard<std::mutex> lk(m->ring->mu);
+    launches = (long long)m->ring->launches; commands = (long long)m->ring->commands;
+  }
+#ifdef DDD_RING_TRACE   // (variant build: where the stamps are)
+  if (m->ring != nullptr) launches = (long long)(uintptr_t)(m->ring->status + 16);
+#endif
+  if (ring_launches != nullptr) *ring_launches = launches;
+  if (ring_commands != nullptr) *ring_commands = commands;
   return DDD_OK;
 }
 

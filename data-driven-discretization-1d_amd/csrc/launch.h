@@ -14,6 +14,7 @@
 #include "dev_params.h"
 
 namespace ddd {
+struct RingArgs;   // ring_args.h
 namespace launch {
 
 // rows: 64 (one-wave groups) or 256; f64: float64 state (rows = 64 only);
@@ -37,6 +38,11 @@ template <int kEq>
 void substep_spec(int rows, const DevParams& p, const SubstepArgs& a, int groups, int grid,
                   hipStream_t stream);
 
+// the same walk under the device-resident command ring (substep_ring_kernel; 64-row groups):
+// mfma_ring.hip, one unit per equation
+template <int kEq>
+void substep_ring_spec(const DevParams& p, const RingArgs& r, int grid, hipStream_t stream);
+
 // all stages of one step in one launch (step_multi_kernel)
 template <int kEq>
 void step_spec(int rows, const DevParams& p, const StepArgs& a, int groups, int grid,
@@ -54,6 +60,7 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
   template <> void adaptive_spec<EQ>(int, const DevParams&, const AdaptiveArgs&, int,          \
                                      hipStream_t);                                             \
   template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
+  template <> void substep_ring_spec<EQ>(const DevParams&, const RingArgs&, int, hipStream_t); \
   template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void adaptive_quad_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);

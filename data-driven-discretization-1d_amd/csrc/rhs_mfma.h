@@ -1572,7 +1572,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     DDD_STAMP(1);
     // A/B (DDD_PRIO_PHASES): the matrix phases of an evaluation at raised issue priority, the
     // VALU phases (epilogue, forcing, Runge-Kutta update) at the lowest
-    if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(3);
+    // (DDD_PRIO_PHASES = 2, round 6: the other way round -- the VALU phases raised, so that a
+    // wavefront's short bookkeeping is not stretched by its SIMD partner's MFMA stream)
+    if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(DDD_PRIO_PHASES == 2 ? 0 : 3);
     // kernels that do not keep the hidden layer resident (four-wave adaptive integrators,
     // run-time kernels): the first hidden layer's 81 operand rows are REQUESTED here, before
     // the input layer, its store and the barrier -- one L2 round trip per evaluation that
@@ -1800,7 +1802,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       }
       }   // !kSplit
       DDD_STAMP(3);
-      if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(0);
+      if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(DDD_PRIO_PHASES == 2 ? 3 : 0);
     }
   } else {
     if (forced && fast_forcing && prepare_next && !(ablate & 1))

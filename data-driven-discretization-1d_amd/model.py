@@ -294,7 +294,9 @@ class _DeviceModel(object):
     """`with model.chained_substeps(): ...` around a caller-owned Runge-Kutta loop
     of rk_substep / time_derivative_rows calls on the current stream
     (ddd_stream_fork .. ddd_stream_join, include/ddd1d.h): large ensembles then
-    advance as two half-ensemble chains that stay alive across the calls.  Inside
+    advance as two half-ensemble chains that stay alive across the calls -- or,
+    after `set_region_mode('ring')`, for the per-equation kernels on one-wave groups,
+    as commands to ONE persistent kernel (the command ring, round 6).  Inside
     the block the arrays handed to those calls must not be touched by anything
     else; after it the current stream is ordered behind every substep."""
     lib = _lib.load_library()
@@ -304,6 +306,22 @@ class _DeviceModel(object):
       yield self
     finally:
       _lib.check(lib.ddd_stream_join(self._handle, stream))
+
+  def set_region_mode(self, mode: str = 'auto'):
+    """How `chained_substeps` regions run: 'auto' / 'chains' (launches) or 'ring' (the
+    command ring where the model has one).  ddd_set_region_mode."""
+    lib = _lib.load_library()
+    _lib.check(lib.ddd_set_region_mode(
+        self._handle, {'auto': 0, 'chains': 1, 'ring': 2}[mode]))
+
+  def region_stats(self):
+    """(persistent-kernel launches, commands) of the command ring so far."""
+    import ctypes
+    lib = _lib.load_library()
+    launches, commands = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.ddd_region_stats(self._handle, ctypes.byref(launches),
+                                    ctypes.byref(commands)))
+    return launches.value, commands.value
 
   def integrate_fixed(self, y0, num_steps: int, dt: Optional[float] = None,
                       t0: float = 0.0, scheme: str = 'midpoint',

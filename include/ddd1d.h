@@ -277,9 +277,37 @@ DDD_API int ddd_rk_substep(ddd_model* model, double t, const float* y_in,
  * the model; calls on another stream, a batch too small to split, and models
  * without a per-equation MFMA kernel simply run on `stream` as without the
  * region.  ddd_stream_join without an open region is a no-op.  Neither call
- * synchronises the host. */
+ * synchronises the host.
+ *
+ * Round 6 -- the command ring (opt-in: ddd_set_region_mode(model, DDD_REGION_RING)).
+ * Models with a per-equation MFMA kernel on one-wave groups (num_points divides 64;
+ * default net) can run the region on ONE persistent kernel: the first ddd_rk_substep
+ * of the region launches it on `stream`, and every call from then on is a 128-byte
+ * command the host writes into a page-locked ring the kernel's wavefronts read -- no
+ * launch, no drain, the conv weights stay in registers across calls.  Same contract as
+ * above (the arrays belong to the region until the join), same bits as one launch per
+ * call.  Measured at the rate of the launches (71.6 vs 71.1 % at 4 096 samples,
+ * profiles/r6_ablation.txt), which is why it is not the default.  What differs:
+ *   - work enqueued on `stream` INSIDE the region is ordered behind the persistent
+ *     kernel, i.e. behind the join -- or behind the moment the region has been idle
+ *     for 2 ms: a park thread then ends the kernel (the next call starts it again),
+ *     so a caller that synchronises the device inside an open region waits that
+ *     long, not for ever;
+ *   - the host may run at most 256 calls ahead of the device; the 257th (and a join
+ *     then) waits for room;
+ *   - a host that stops for 20 s while the kernel waits (a debugger) trips the
+ *     kernel's watchdog: the next call returns DDD_ERR_HIP and the region's results
+ *     are undefined.
+ * ddd_set_region_mode chooses: DDD_REGION_AUTO (default) and DDD_REGION_CHAINS = the
+ * two chains of launches; DDD_REGION_RING = the ring where the model has one, else the
+ * chains.  It closes an open region.  ddd_region_stats: persistent-kernel launches and
+ * commands so far. */
+enum ddd_region_mode { DDD_REGION_AUTO = 0, DDD_REGION_CHAINS = 1, DDD_REGION_RING = 2 };
 DDD_API int ddd_stream_fork(ddd_model* model, void* stream);
 DDD_API int ddd_stream_join(ddd_model* model, void* stream);
+DDD_API int ddd_set_region_mode(ddd_model* model, int mode);
+DDD_API int ddd_region_stats(const ddd_model* model, int64_t* ring_launches,
+                             int64_t* ring_commands);
 
 /* Replaces: model.integrate_ode (model.py:138-159) and, with the controller
  * pinned at max_step, the solve_ivp loop of integrate.odeint

@@ -82,10 +82,15 @@ for name, c in line['configs'].items():
   if name == 'rk_substep_external':
     for b in ('b4096', 'b8192'):
       e = c[b]
-      P('  %-20s %-6s C loop chained %.1f %% (%.1f us per call) | Python chained %.1f %% | Python unchained %.1f %% | '
+      launches = e.get('c_loop_command_ring')
+      P('  %-20s %-6s C loop chained %.1f %% (%.1f us per call%s) | Python chained %.1f %% | %sPython unchained %.1f %% | '
         'bit-identical %s' % (name, b, 100 * e['c_loop_chained']['frac'],
                               e['c_loop_chained']['us_per_substep_call'],
+                              '',
                               100 * e['python_loop_chained']['frac'],
+                              'C loop on the command ring %.1f %% (%d persistent launches for %d calls) | ' % (
+                                  100 * launches['frac'], e['ring']['persistent_kernel_launches'],
+                                  e['ring']['commands']) if launches else '',
                               100 * e['python_loop_unchained']['frac'],
                               e['drivers_bit_identical'] and e['equals_ddd_integrate_fixed_per_substep']))
   elif 'achieved' in c:
