@@ -89,7 +89,7 @@ CONFIG_NAMES = ('kdv_n64_b4096', 'ks_n256_b8192', 'burgers_per_substep', 'burger
                 # round 6: like-for-like partners of the adaptive / fixed-step KS legs, the
                 # production integrator on a small ensemble, the WENO5 exact solver
                 'adaptive_ks_n256_b8192', 'ks_n256_b1024', 'adaptive_rk23_b256', 'burgers_b512',
-                'weno_exact_n512_b2048')
+                'weno_exact_n512_b2048', 'tower_f16_b4096')
 
 
 def parse_args(argv=None):
@@ -975,6 +975,14 @@ def extra_configs(args, lib, world):
             '(training.py:134-136 leaves them free): the MFMA towers with streamed weights; '
             'fractions in TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
             **dict(base, hparams=json.dumps(hp), steps=200))
+      elif name == 'tower_f16_b4096':
+        hp = {'filter_size': 16}
+        key, val = _fixed_step_config(
+            args, lib, world, name, 'the headline workload with hyper-parameters {} '
+            '(training.py:134-136 leaves them free): the block-diagonal tower of nets with up to 16 '
+            'filters (rhs_mfma.h HalfTower; round 5: embedded in 32 filters, 25.7 %); fractions in '
+            'TRUE-net FLOPs'.format(json.dumps(hp)), 4096,
+            **dict(base, hparams=json.dumps(hp), steps=500))
       elif name == 'one_layer_b4096':
         key, val = _fixed_step_config(
             args, lib, world, name, 'num_layers = 1 (a hyper-parameter create_hparams admits; '

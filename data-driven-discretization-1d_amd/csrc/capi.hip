@@ -53,6 +53,7 @@ struct DebugOptions {
   int no_lean = 0;       // the MFMA-path kernels (tower skipped) instead of rhs_lean.h
   int no_weno = 0;       // the generic kernel instead of rhs_weno.h
   int no_fft = 0;        // spectral models: the O(N^2) circulant form at every N
+  int no_half = 0;       // nets of <= 16 filters: embedded in 32 instead of the block-diagonal tower
   int prio_split = 0;    // A/B: static wave priorities
   int stagger = 0;       // A/B: initial s_sleep of odd wave slots
   int substep_parts = 0; // A/B: sample slabs advanced side by side in the per-substep modes (0: auto)
@@ -295,6 +296,9 @@ struct ddd_model {
   float* d_w_final4_rt = nullptr;
   float* d_w_final4_split = nullptr;
   float* d_w_quad = nullptr;
+  float* d_w_hidden_half = nullptr;   // block-diagonal packing of a <= 16-filter net (rhs_mfma.h HalfTower)
+  float* d_w_final4_half = nullptr;
+  bool last_launch_half = false;
   bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
   bool split_auto = true;            // small ensembles: two 32-row wavefronts per sample (kSplit)
   int tower_k = 5, tower_cb = 1;     // conv tower the MFMA kernels carry the net in (rhs_mfma.h Tower)
@@ -782,6 +786,45 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
         if (rc) return rc;
         m->dp.w_quad = m->d_w_quad;
       }
+      // ... and, for nets of up to 16 filters (embedded here in 32), the BLOCK-DIAGONAL packing
+      // of rhs_mfma.h HalfTower: the hidden layer's panel with output rows 16..31 = the same 16
+      // channels fed by reduction half 1, and the output layer over 5 x 16 + 1 reduction steps.
+      // Source: the embedded net (channels >= 16 are zero there).
+      if (dp.L == 3 && dp.cout[0] <= 16 && m->dp.fin4_groups <= 4) {
+        using namespace ddd::mfma;
+        const float* w1 = weights + net.w_off[1];   // [5][32][32]
+        const float* b1 = weights + net.b_off[1];
+        std::vector<float> hid((size_t)kHidSteps * 64, 0.0f);
+        for (int s2 = 0; s2 < 80; ++s2) {
+          const int tap = s2 / 16, jj = s2 % 16;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int mrow = lane & 31, half = lane >> 5;
+            if ((mrow < 16) == (half == 0))
+              hid[(size_t)s2 * 64 + lane] = w1[(tap * 32 + jj) * 32 + (mrow & 15)];
+          }
+        }
+        for (int lane = 0; lane < 32; ++lane) hid[(size_t)80 * 64 + lane] = dn * b1[lane & 15];
+        rc = upload(quad_rows(hid.data(), kHidSteps), &m->d_w_hidden_half);
+        if (rc) return rc;
+        const float* w = m->spec_folded ? wf.data() : w_nat;
+        const float* b = m->spec_folded ? bf.data() : b_nat;
+        const int cout_n = m->spec_folded ? fold_cols : dp.C_out;
+        const int n_ch = m->spec_folded ? dp.D * dp.G : dp.C_out;
+        const int groups = m->dp.fin4_groups;
+        std::vector<float> fin((size_t)fin4_regs(4) * 64, 0.0f);
+        for (int k = 0; k <= 80; ++k)   // k = 16 tap + cin, 80: bias
+          for (int grp = 0; grp < groups; ++grp) {
+            const int q = k * groups + grp;
+            for (int r = 0; r < 4; ++r) {
+              const int ch = 4 * grp + r;
+              if (ch >= n_ch || ch >= cout_n) continue;
+              fin[(size_t)(q / 16) * 64 + 4 * (q % 16) + r] =
+                  k < 80 ? up * w[(size_t)((k / 16) * 32 + (k % 16)) * cout_n + ch] : b[ch];
+            }
+          }
+        rc = upload(quad_rows(fin.data(), fin4_regs(4)), &m->d_w_final4_half);
+        if (rc) return rc;
+      }
     }
   }
   return DDD_OK;
@@ -856,6 +899,15 @@ void decide_mfma(ddd_model* m) {
     m->tower_k = dp.K <= 3 ? 3 : dp.K <= 5 ? 5 : 7;
     m->tower_cb = dp.F <= 32 ? 1 : 2;
     if (m->tower_cb == 2 && m->tower_k == 3) m->tower_k = 5;   // (64-filter towers: 5 and 7 taps)
+    // up to 16 filters of up to 3 taps in the architecture of the per-equation kernels: the
+    // 5 x 32 tower, whose persistent integrators carry such nets block-diagonally (rhs_mfma.h
+    // HalfTower: half the hidden-layer MFMAs of the embedding) -- ahead of the 3-tap tower,
+    // where they would occupy a quarter of every MFMA
+    if (m->tower_k == 3 && dp.F <= 16 && dp.L == 3 && dp.act == ddd::ACT_RELU && !wide &&
+        dp.target == ddd::TARGET_COEFFICIENTS && dp.pao > 0 &&
+        dp.equation >= ddd::EQ_BURGERS && dp.equation <= ddd::EQ_KS_CONS &&
+        dp.G == ddd::mfma::spec_stencil(dp.equation))
+      m->tower_k = 5;
     if (dp.F > 64) no("filter_size > 64");
     if (dp.K > 7) no("kernel_size > 7");
     if (dp.L < 2) no("fewer than 2 conv layers");
@@ -1034,7 +1086,7 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     return DDD_OK;
   }
   m->last_launch_streamed = false; m->last_launch_lean = false;
-  m->last_launch_split = false; m->last_launch_quad = false;
+  m->last_launch_split = false; m->last_launch_quad = false; m->last_launch_half = false;
   if (m->kernel == DDD_KERNEL_MFMA) {
     m->dp.dpp_rol = dpp_wave_rol_ok();
     ddd::DevParams dp = m->dp;
@@ -1121,9 +1173,16 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
     if (!traced) eq = -1;
   }
 #endif
+  // nets of up to 16 filters: the block-diagonal tower (float32 state, one-wave groups)
+  const bool half = kRows == 64 && kWR == 64 && !f64 && !traced && eq >= 0 &&
+                    m->d_w_hidden_half != nullptr && m->d_w_final4_half != nullptr && !g_debug.no_half;
+  m->last_launch_half = half;
+  ddd::DevParams dp_half = m->dp;
+  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; }
 #define DDD_SPEC_CASE(EQ)                                                              \
   case EQ:                                                                             \
-    if (kWR == 16) ddd::launch::integrate_quad_spec<EQ>(m->dp, a, blocks, stream);     \
+    if (half) ddd::launch::integrate_half_spec<EQ>(dp_half, a, blocks, stream);        \
+    else if (kWR == 16) ddd::launch::integrate_quad_spec<EQ>(m->dp, a, blocks, stream);     \
     else if (kWR == 32) ddd::launch::integrate_split_spec<EQ>(m->dp, a, blocks, stream); \
     else ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); \
     return;
@@ -1196,7 +1255,7 @@ int launch_integrate(ddd_model* m, ddd::IntegrateArgs a, hipStream_t stream) {
   a.ablate = g_debug.ablate;
 #endif
   m->last_launch_split = false;
-  m->last_launch_quad = false;
+  m->last_launch_quad = false; m->last_launch_half = false;
   if (m->kernel == DDD_KERNEL_MFMA && std::is_same<ST, float>::value && !m->explicit_kernel &&
       !g_debug.no_lean && launch_lean(m, a, stream)) {
     // fixed stencils / one-layer nets, float32 state, whole samples per wavefront: the
@@ -1471,7 +1530,7 @@ int ring_post(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream) {
   rg->last_post = std::chrono::steady_clock::now();
   m->last_batch = a.batch;
   m->last_launch_streamed = false; m->last_launch_lean = false;
-  m->last_launch_split = false; m->last_launch_quad = false;
+  m->last_launch_split = false; m->last_launch_quad = false; m->last_launch_half = false;
   return DDD_OK;
 }
 
@@ -1882,6 +1941,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
+  free_dev(m->d_w_hidden_half); free_dev(m->d_w_final4_half);
   free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_w_final4_split); free_dev(m->d_w_quad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
@@ -2131,6 +2191,7 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
   const float h = (float)dt;
   const ddd::StageConsts stage_consts = make_stage_consts(tab, dt);
 
+  m->last_launch_half = false; m->last_launch_quad = false; m->last_launch_split = false;
   // large ensembles: two half-ensembles side by side (plan_slabs)
   const SlabPlan plan = plan_slabs(m, batch);
   const int halves = plan.halves;
@@ -2397,7 +2458,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   a.max_attempts = max_attempts;
   m->last_batch = batch;
   m->last_launch_streamed = false; m->last_launch_lean = false;
-  m->last_launch_split = false; m->last_launch_quad = false;
+  m->last_launch_split = false; m->last_launch_quad = false; m->last_launch_half = false;
   if (m->spectral) {
     // float64 right-hand side (SpectralDifferentiator), one workgroup per sample
     const size_t lds = ddd::spectral::lds_bytes(m->sp);
@@ -2444,7 +2505,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
   // small ensembles: every 64-row group on four 16-row wavefronts (rhs_mfma.h kQuad), as
   // launch_integrate chooses it for the fixed-step integrators -- the reference's callers
   // integrate tens to hundreds of samples (scripts/run_evaluation.py:212-221)
-  m->last_launch_quad = false;
+  m->last_launch_quad = false; m->last_launch_half = false;
   if (want_quad && m->dp.w_quad != nullptr && spec_equation(m, 64) >= 0 &&
       (m->force_rows == 16 || (m->split_auto && !m->explicit_kernel && 2 * blocks <= device_simds()))) {
     m->last_launch_quad = true;
@@ -2661,6 +2722,7 @@ const char* ddd_kernel_name(const ddd_model* m) {
   const MfmaGeometry geo = mfma_geometry(m, m->last_batch > 0 ? m->last_batch : 1 << 30);
   if (geo.rows == 256) return "mfma_f32_r256";
   if (m->last_launch_quad) return "mfma_f32_r64w16";
+  if (m->last_launch_half) return "mfma_f32_r64h16";
   return (geo.wave_rows == 32 || m->last_launch_split) ? "mfma_f32_r64w32" : "mfma_f32_r64";
 }
 
@@ -2680,6 +2742,7 @@ DDD_API int ddd_debug_set_option(const char* name, long long value) {
   else if (key == "no_lean") g_debug.no_lean = (int)value;
   else if (key == "no_weno") g_debug.no_weno = (int)value;
   else if (key == "no_fft") g_debug.no_fft = (int)value;
+  else if (key == "no_half") g_debug.no_half = (int)value;
   else if (key == "prio_split") g_debug.prio_split = (int)value;
   else if (key == "stagger") g_debug.stagger = (int)value;
   else if (key == "substep_parts") g_debug.substep_parts = (int)value;

@@ -30,6 +30,10 @@ void integrate_split_spec(const DevParams& p, const IntegrateArgs& a, int blocks
 template <int kEq>
 void integrate_quad_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
                          hipStream_t stream);
+// nets of up to 16 filters on the block-diagonal tower (rhs_mfma.h HalfTower; one-wave groups,
+// float32 state): mfma_half.hip, one unit per equation
+template <int kEq>
+void integrate_half_spec(const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream);
 // ... and the adaptive RK23 on the same four-wavefront groups
 template <int kEq>
 void adaptive_quad_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
@@ -61,6 +65,7 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
                                      hipStream_t);                                             \
   template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
   template <> void substep_ring_spec<EQ>(const DevParams&, const RingArgs&, int, hipStream_t); \
+  template <> void integrate_half_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void adaptive_quad_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);

@@ -91,15 +91,36 @@ struct Tower {
   static constexpr int kInSteps = (kK_ + 2) / 2;    // (taps + bias) / 2, rounded up
   static constexpr int kHidK = kK_ * kC / 2;        // 32x32x2 steps per output block (without bias)
   static constexpr int kHidGroups = kHidK / 4;      // ... in groups of four (one float4 of weights)
+  static constexpr int kFinC = kC;                  // channels the output layer reduces over per tap
   static constexpr int kFinK = kK_ * kC + 1;        // 4x4x1 reduction steps of the output layer (+ bias)
   static constexpr int kOperandGroups = kK_ * kC / 4;   // ds_read_b128 per lane in the output layer
   static constexpr bool kDefault = kK_ == 5 && kCB_ == 1;
+  static constexpr bool kHalf = false;              // (HalfTower below)
   // 7 taps x 64 filters: the hidden layer runs as a loop over the taps (hidden_layer_rolled);
   // fully unrolled its 896 MFMAs per layer and kernel took > 20 minutes to compile
   static constexpr bool kRolled = kK_ * kCB_ >= 14;
   static_assert(kK_ % 2 == 1 && kK_ >= 3 && kK_ <= 7 && kCB_ >= 1 && kCB_ <= 2, "tower geometry");
 };
 typedef Tower<kKW, 1> DefaultTower;
+// Nets of up to 16 filters (filter_size <= 16, training.py:134-136 leaves it free) in the
+// default tower's layout, BLOCK-DIAGONAL (round 6): embedded with zero weights they occupy a
+// quarter of every 32 x 32 x 2 MFMA of the hidden layer (16 of 32 output rows x 16 of 32
+// reduction channels: 25.7 % of the issued work is the net's).  Here one MFMA pass carries
+// BOTH 32-position tiles of the wavefront: output rows 0..15 = the 16 channels at positions
+// j, rows 16..31 = the same channels at positions 32 + j; reduction half 0 = the 16 input
+// channels at the tap rows of position j, half 1 = those of position 32 + j, the weight
+// panel block-diagonal.  Half the hidden-layer MFMAs (81 instead of 162), and the output
+// layer reduces over 5 x 16 + 1 instead of 5 x 32 + 1 steps.  Every accumulation chain keeps
+// the embedded evaluation's order (the products dropped are exact zeros): the same bits.
+// LDS layout, input layer and everything outside the tower: the default tower's.
+struct HalfTower {
+  static constexpr int kK = kKW, kCB = 1, kC = 32, kHS = 36, kInSteps = 3;
+  static constexpr int kHidK = kKW * 32 / 2, kHidGroups = kHidK / 4;
+  static constexpr int kFinC = 16;
+  static constexpr int kFinK = kKW * kFinC + 1;
+  static constexpr int kOperandGroups = kKW * kFinC / 4;
+  static constexpr bool kDefault = true, kRolled = false, kHalf = true;
+};
 // floats of one hidden layer in the streamed layout: [group][out block][lane] float4, then the
 // bias rows [out block][lane]
 template <class TW>
@@ -118,8 +139,21 @@ __host__ __device__ constexpr int fin4_regs_t(int groups) { return (TW::kFinK * 
 // per SIMD (single activation buffer: 11.9 KB of LDS, 168 VGPRs, two resident weight groups)
 // measured below two wavefronts with the whole hidden layer resident (241 VGPRs): 62.9 vs
 // 64.4 % at 4 096 samples, 39.7 vs 50.5 % with one launch per substep.
+// Issue priority by phase (s_setprio; prio_mode(kEq) below).  0: none (rounds 1-5; the
+// run-time-parameterised kernels).  1 (round 5): the matrix layers raised, the VALU phases at 0
+// -- neutral.  2 (round 6): the other way round -- a wavefront's VALU phases (epilogue,
+// forcing, Runge-Kutta update, the adaptive controller) raised, its matrix layers at 0: next
+// to a SIMD partner that streams MFMAs a short VALU burst costs the partner nothing (the
+// matrix pipe is busy with its last MFMA for 64 cycles anyway) and gets this wavefront back to
+// its own MFMAs sooner.  3: as 2, and only the steady middle of the hidden / output layers at
+// 0 -- their first and last operand groups, relu and the activation stores raised as well.
+// Measured (profiles/r6_ablation.txt; fractions of 157.3 TFLOP/s, mode 0 / 2 / 3):
+//   KdV N=64 84.3 / 84.7 / 88.0    adaptive KdV 76.0 / 76.4 / 78.6    KS N=256 82.8 / 83.5 / 83.7
+//   Burgers (headline) 82.1 / 81.9 / 81.8    adaptive Burgers 76.4 / 77.0 / 76.7
+// -> per-equation kernels: 3 where the evaluation carries no forcing phases (KdV, KS), 2 in
+//    the Burgers family.  4 (A/B): 3 with the forcing phases inside the matrix layers at 0.
 #ifndef DDD_PRIO_PHASES
-#define DDD_PRIO_PHASES 0   // measured neutral (profiles/r5_ablation.txt): off
+#define DDD_PRIO_PHASES (-1)   // -1: by equation (prio_mode)
 #endif
 #ifndef DDD_K3_WAVES
 #define DDD_K3_WAVES 2
@@ -218,6 +252,9 @@ __host__ __device__ constexpr int spec_stencil(int eq) { return spec_flux_form(e
 // the other specialised kernels carry no forcing code at all.
 __host__ __device__ constexpr bool spec_forced_family(int eq) {
   return eq == EQ_BURGERS || eq == EQ_BURGERS_CONS;
+}
+__host__ __device__ constexpr int prio_mode(int eq) {
+  return DDD_PRIO_PHASES >= 0 ? DDD_PRIO_PHASES : eq < 0 ? 0 : spec_forced_family(eq) ? 2 : 3;
 }
 // Null-space sizes of the accuracy layers at the defaults the specialised
 // kernels assume (polynomial_accuracy_order 1, coefficient_grid_min_size 6;
@@ -606,7 +643,9 @@ __device__ __forceinline__ void input_layer(const DevParams& p, const Lane& ln,
 // g + 1 is issued before the four MFMAs of group g (software prefetch).
 // kByteOffsets: `rows` already holds the LDS byte offsets of the operand rows
 // (row * 144 + 64 * half; kept resident by the specialised one-wave integrators).
-template <int kWR, bool kByteOffsets = false>
+// kHalfNet (HalfTower: called with kWR = 32, i.e. ONE tile): the tile's output rows 16..31 are
+// the channels of position 32 + j -- registers 8..15 go to that row.
+template <int kWR, bool kByteOffsets = false, bool kHalfNet = false, int kPrio = 0>
 __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
                                              const float* __restrict__ in,
                                              float* __restrict__ out,
@@ -639,6 +678,8 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
   __builtin_amdgcn_sched_group_barrier(0x100, kT, 0);     // the reads of group 0
 #pragma unroll
   for (int g = 0; g < 20; ++g) {
+    if (kPrio >= 3 && g == 1) __builtin_amdgcn_s_setprio(0);
+    if (kPrio >= 3 && g == 19) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < kT; ++t) {
       nxt[t] = cur[t];
@@ -665,7 +706,14 @@ __device__ __forceinline__ void hidden_layer(const DevParams& p, const Lane& ln,
 #pragma unroll
   for (int t = 0; t < kT; ++t) {
     activate16(acc[t], act);
-    if (kByteOffsets) store_tile32_at_bytes(out, st_off + t * 32 * kHS * 4, acc[t]);
+    if constexpr (kHalfNet) {
+      static_assert(kByteOffsets && kT == 1, "block-diagonal nets: one tile, resident offsets");
+      char* orow = reinterpret_cast<char*>(out) + st_off;   // row j, + 16 half
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)   // registers 4 qd ..: channels (qd & 1) 8 + 4 half + 0..3 of row j + 32 (qd >> 1)
+        *reinterpret_cast<float4*>(orow + (qd >> 1) * 32 * kHS * 4 + 32 * (qd & 1)) = make_float4(
+            acc[t][4 * qd + 0], acc[t][4 * qd + 1], acc[t][4 * qd + 2], acc[t][4 * qd + 3]);
+    } else if (kByteOffsets) store_tile32_at_bytes(out, st_off + t * 32 * kHS * 4, acc[t]);
     else store_tile32(out, ln.wave * kWR + t * 32 + j, half, acc[t]);
   }
 }
@@ -1239,7 +1287,7 @@ __device__ __forceinline__ void fin4_step(const char* __restrict__ in, const int
                                           const float (&w)[fin4_regs_t<TW>(NG)],
                                           f32x4 (&buf)[kFin4Ahead + 1], f32x4 (&acc)[kAcc]) {
   constexpr int kNext = OG + kFin4Ahead;
-  constexpr int kPerTap = TW::kC / 4;
+  constexpr int kPerTap = TW::kFinC / 4;
   if constexpr (kNext < TW::kOperandGroups)
     buf[kNext % (kFin4Ahead + 1)] =
         *reinterpret_cast<const f32x4*>(in + off[kNext / kPerTap] + 16 * (kNext % kPerTap));
@@ -1258,12 +1306,12 @@ __device__ __forceinline__ void fin4_run(const char* __restrict__ in, const int 
 }
 
 // `off`: LDS byte offsets (row * kHS * 4) of the lane's tap rows.
-template <int NG, class TW = DefaultTower, int kAcc = NG>
+template <int NG, class TW = DefaultTower, int kAcc = NG, int kPrio = 0>
 __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
                                              const float (&w)[fin4_regs_t<TW>(NG)],
                                              const int (&off)[TW::kK], f32x4 (&acc)[kAcc]) {
   const char* __restrict__ in = reinterpret_cast<const char*>(in_f);
-  constexpr int kPerTap = TW::kC / 4;
+  constexpr int kPerTap = TW::kFinC / 4;
   f32x4 buf[kFin4Ahead + 1];
 #pragma unroll
   for (int g = 0; g < kAcc; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1271,7 +1319,9 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
   for (int og = 0; og < kFin4Ahead; ++og)
     buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / kPerTap] + 16 * (og % kPerTap));
   __builtin_amdgcn_sched_group_barrier(0x100, kFin4Ahead, 0);
+  if (kPrio >= 3) __builtin_amdgcn_s_setprio(0);
   fin4_run<NG, TW, kAcc>(in, off, w, buf, acc, std::make_integer_sequence<int, TW::kOperandGroups>{});
+  if (kPrio >= 3) __builtin_amdgcn_s_setprio(3);
   // bias row: k = K C against a constant 1
   fin4_mfmas<NG, (TW::kFinK - 1) * NG, fin4_regs_t<TW>(NG), kAcc>(
       w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc, std::make_integer_sequence<int, NG>{});
@@ -1435,6 +1485,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   const int nL = kHoist ? 3 : p.L;
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
+  constexpr int kPrio = prio_mode(kEq);
   // output-channel groups of four (final_layer4): the specialised kernels issue
   // their live ones as one compile-time interleaved stream (channels renumbered
   // contiguously, DevParams::w_final4); the run-time-parameterised kernels
@@ -1574,7 +1625,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     // VALU phases (epilogue, forcing, Runge-Kutta update) at the lowest
     // (DDD_PRIO_PHASES = 2, round 6: the other way round -- the VALU phases raised, so that a
     // wavefront's short bookkeeping is not stretched by its SIMD partner's MFMA stream)
-    if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(DDD_PRIO_PHASES == 2 ? 0 : 3);
+    if (kPrio) __builtin_amdgcn_s_setprio(kPrio == 2 ? 0 : 3);   // (3: stays raised)
     // kernels that do not keep the hidden layer resident (four-wave adaptive integrators,
     // run-time kernels): the first hidden layer's 81 operand rows are REQUESTED here, before
     // the input layer, its store and the barrier -- one L2 round trip per evaluation that
@@ -1591,7 +1642,11 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
                                                act, res.in_perm, res.st_off);
     }
     const bool frc_next = forced && fast_forcing && prepare_next && !(ablate & 1);
-    if (frc_next) forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
+    if (frc_next) {
+      if (kPrio == 4) __builtin_amdgcn_s_setprio(0);
+      forcing_phase1<kRows, kWR>(p, sm, res, t_next, tid);
+      if (kPrio == 4) __builtin_amdgcn_s_setprio(3);
+    }
     float* in = sm.hA;
     float* out = Shared<kRows, kWR, kWide, TW>::kSingleBuffer ? sm.hA : sm.hB;
     for (int l = 1; l < nL - 1; ++l) {
@@ -1610,7 +1665,12 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       } else {
         if (!kHoist && l > 1) load_hidden(p, l - 1, ln.lane, res.hid);   // (layer 1: requested above)
         group_barrier<kRows, kWR>();
-        hidden_layer<kWR, kKeepOffsets>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
+        if constexpr (TW::kHalf) {
+          static_assert(kKeepOffsets && kWR == 64 && kOneWave, "block-diagonal nets: resident one-wave integrators");
+          hidden_layer<32, true, true, kPrio>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
+        } else {
+          hidden_layer<kWR, kKeepOffsets, false, kPrio>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
+        }
       }
       float* tmp = in; in = out; out = tmp;
     }
@@ -1675,7 +1735,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
           net[4 * g4] = v.x; net[4 * g4 + 1] = v.y; net[4 * g4 + 2] = v.z; net[4 * g4 + 3] = v.w;
         }
       } else {
-      constexpr int kFirstRows = kSpec ? fin4_regs(kNG) : fin4_regs_t<TW>(3);
+      constexpr int kFirstRows = kSpec ? fin4_regs_t<TW>(kNG) : fin4_regs_t<TW>(3);
       float wf4[kFirstRows];
       if (!kKeepRows) {
         if constexpr (kSpec) {
@@ -1713,12 +1773,16 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       // (masked sums where registers allow: the folded kernels; the unfolded
       // non-flux Burgers kernel needs them for the projection)
       constexpr bool kMaskedSums = kKeepRows && spec_folded(kSpec ? kEq : 0);
-      if (frc_next) res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
+      if (frc_next) {
+        if (kPrio == 4) __builtin_amdgcn_s_setprio(0);
+        res.fk_next = forcing_phase2<kRows, kWR, kMaskedSums>(sm, res);
+        if (kPrio == 4) __builtin_amdgcn_s_setprio(3);
+      }
       group_barrier<kRows, kWR>();
       if constexpr (kSpec) {
         f32x4 acc4[kNG];
         if (!(ablate & 4)) {
-          final_layer4<kNG>(in, wf4, off4, acc4);
+          final_layer4<kNG, TW, kNG, kPrio>(in, wf4, off4, acc4);
         } else {
 #pragma unroll
           for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -1802,7 +1866,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       }
       }   // !kSplit
       DDD_STAMP(3);
-      if (DDD_PRIO_PHASES) __builtin_amdgcn_s_setprio(DDD_PRIO_PHASES == 2 ? 3 : 0);
+      if (kPrio) __builtin_amdgcn_s_setprio(kPrio >= 2 ? 3 : 0);
     }
   } else {
     if (forced && fast_forcing && prepare_next && !(ablate & 1))
@@ -2125,7 +2189,7 @@ __device__ __forceinline__ int forcing_batches(const DevParams& p) {
 // (Resident::fin4_off .. pch_idx): functions of the lane, N and G alone.
 // (Loading them from a per-model table instead -- 115 VALU instructions fewer per
 // launch -- changed nothing measurable: profiles/r3_ablation.txt.)
-template <int kRows, int kWR>
+template <int kRows, int kWR, bool kHalfNet = false>
 __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln, Resident& res) {
   int rows[kKW];
   if constexpr (kWR == 16) {
@@ -2165,6 +2229,17 @@ __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln,
     for (int k = 0; k < kKW; ++k)
       res.hid_off[t2][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) +
                                   64 * half);
+    if constexpr (kHalfNet) {
+      // block-diagonal nets: ONE tile; reduction half h reads channels 0..15 of the tap rows
+      // of position 32 h + j
+      if (t2 == 0) {
+        int rows_h[kKW];
+        tap_rows<kRows == 64>(ln, ln.wave * kWR + ln.lane, p.N, rows_h);   // (lane = 32 half + j)
+#pragma unroll
+        for (int k = 0; k < kKW; ++k)
+          res.hid_off[0][k] = opaque((int)__umul24((unsigned)rows_h[k], (unsigned)(kHS * 4)));
+      }
+    }
     // input layer: taps 0 / 1, taps 2 / 3, tap 4, as byte addresses (one-wave
     // groups: ds_bpermute lane addresses, rows < 64; else into Shared::un)
     res.in_perm[t2][0] = opaque(4 * (half ? rows[1] : rows[0]));
@@ -2280,7 +2355,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   res.fk_off = opaque(ln.sl * kTrigMax * 4);   // (fixed-stencil models with forcing read it too)
   res.st_off = 0;
   if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || kWR == 16 || p.w_final4_split != nullptr))
-    lane_offsets<kRows, kWR>(p, ln, res);
+    lane_offsets<kRows, kWR, TW::kHalf>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
     sm.pm[i] = make_float2(0.0f, 0.0f);

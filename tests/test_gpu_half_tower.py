@@ -1,0 +1,73 @@
+"""Nets of up to 16 filters on the block-diagonal tower (csrc/rhs_mfma.h HalfTower, round 6;
+training.py:134-136 leaves filter_size free, model.py:455-458 builds whatever it says): one
+MFMA pass of the hidden layer carries both 32-position tiles of a wavefront.  Same bits as the
+zero-padded embedding in 32 filters (the launch modes that still use it), oracle parity at
+1e-5, NaN mask of the reference."""
+import numpy as np
+import pytest
+
+from helpers import batch_forcing, make_model, oracle, random_phase_ic, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.mark.parametrize('equation,conservative,overrides', [
+    ('burgers', True, dict(filter_size=16)),
+    ('burgers', False, dict(filter_size=12, kernel_size=3)),
+    ('kdv', True, dict(filter_size=16)),
+    ('kdv', False, dict(filter_size=8)),
+    ('ks', True, dict(filter_size=16, kernel_size=4)),
+    ('ks', False, dict(filter_size=5)),
+])
+def test_block_diagonal_tower(equation, conservative, overrides):
+  import torch
+  model = make_model(equation, conservative, num_points=64, resample_factor=2, **overrides)
+  batch = 2100   # every SIMD holds 64-row wavefronts (small ensembles take the four-wave kernels)
+  forcing = batch_forcing(batch) if equation == 'burgers' else None
+  if forcing is not None:
+    model.set_forcing(forcing)
+  y0_host = random_phase_ic(model.equation, batch)
+  y0 = torch.from_numpy(y0_host).cuda()
+  dt = model.equation.time_step
+  steps = 12
+  got = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps)[0].cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
+  # the other launch modes run the same net embedded in 32 filters: the same bits
+  for mode in ('per_step', 'per_substep'):
+    other = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
+                                  launch_mode=mode)[0].cpu().numpy()
+    assert model.kernel_name == 'mfma_f32_r64', (mode, model.kernel_name)
+    np.testing.assert_array_equal(got, other)
+  rk4 = model.integrate_fixed(y0, 5, dt=dt, scheme='rk4', save_every=5)[0].cpu().numpy()
+  rk4_step = model.integrate_fixed(y0, 5, dt=dt, scheme='rk4', save_every=5,
+                                   launch_mode='per_step')[0].cpu().numpy()
+  np.testing.assert_array_equal(rk4, rk4_step)
+  rows = np.array([0, 1, batch // 2, batch - 1])
+  sub = None if forcing is None else {k: v[rows] for k, v in forcing.items()}
+  ref = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps, steps,
+                               y0_host[rows], forcing=sub)
+  assert rel_err(got[rows], ref[0]) < TOL
+  # float64 state stays on the embedded route
+  model.integrate_fixed(y0.double(), 2, dt=dt, scheme='midpoint', save_every=2, state_dtype='float64')
+  assert model.kernel_name == 'mfma_f32_r64', model.kernel_name
+
+
+def test_block_diagonal_tower_nan_mask():
+  """A NaN in one sample: the rows the reference's relu would poison (integrate.py:161-167
+  signals divergence by NaN rows), nothing else -- as on the embedded route."""
+  import torch
+  model = make_model('burgers', True, num_points=64, resample_factor=2, filter_size=16)
+  batch = 2100
+  model.set_forcing(batch_forcing(batch))
+  y0_host = random_phase_ic(model.equation, batch)
+  y0_host[7, 20] = np.nan
+  y0 = torch.from_numpy(y0_host).cuda()
+  dt = model.equation.time_step
+  got = model.integrate_fixed(y0, 1, dt=dt, scheme='euler', save_every=1)[0].cpu().numpy()
+  assert model.kernel_name == 'mfma_f32_r64h16'
+  other = model.integrate_fixed(y0, 1, dt=dt, scheme='euler', save_every=1,
+                                launch_mode='per_step')[0].cpu().numpy()
+  np.testing.assert_array_equal(np.isnan(got), np.isnan(other))
+  assert np.isnan(got[7]).any() and not np.isnan(np.delete(got, 7, axis=0)).any()
+  np.testing.assert_array_equal(got[~np.isnan(got)], other[~np.isnan(other)])
