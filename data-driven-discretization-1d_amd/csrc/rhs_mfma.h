@@ -150,8 +150,11 @@ __host__ __device__ constexpr int fin4_regs_t(int groups) { return (TW::kFinK * 
 // Measured (profiles/r6_ablation.txt; fractions of 157.3 TFLOP/s, mode 0 / 2 / 3):
 //   KdV N=64 84.3 / 84.7 / 88.0    adaptive KdV 76.0 / 76.4 / 78.6    KS N=256 82.8 / 83.5 / 83.7
 //   Burgers (headline) 82.1 / 81.9 / 81.8    adaptive Burgers 76.4 / 77.0 / 76.7
-// -> per-equation kernels: 3 where the evaluation carries no forcing phases (KdV, KS), 2 in
-//    the Burgers family.  4 (A/B): 3 with the forcing phases inside the matrix layers at 0.
+// 4 (A/B): 3 with the forcing phases inside the matrix layers at 0 -- no change.  5: 3 with the
+// output layer's middle at 1 instead of 0 (its 8-cycle MFMAs ahead of the partner's 64-cycle
+// ones): KdV 88.4 -> 89.1, KS 84.2 -> 84.4, Burgers unchanged.
+// -> per-equation kernels: 5 where the evaluation carries no forcing phases (KdV, KS), 2 in
+//    the Burgers family.
 #ifndef DDD_PRIO_PHASES
 #define DDD_PRIO_PHASES (-1)   // -1: by equation (prio_mode)
 #endif
@@ -254,7 +257,7 @@ __host__ __device__ constexpr bool spec_forced_family(int eq) {
   return eq == EQ_BURGERS || eq == EQ_BURGERS_CONS;
 }
 __host__ __device__ constexpr int prio_mode(int eq) {
-  return DDD_PRIO_PHASES >= 0 ? DDD_PRIO_PHASES : eq < 0 ? 0 : spec_forced_family(eq) ? 2 : 3;
+  return DDD_PRIO_PHASES >= 0 ? DDD_PRIO_PHASES : eq < 0 ? 0 : spec_forced_family(eq) ? 2 : 5;
 }
 // Null-space sizes of the accuracy layers at the defaults the specialised
 // kernels assume (polynomial_accuracy_order 1, coefficient_grid_min_size 6;
@@ -1278,7 +1281,10 @@ __device__ __forceinline__ void load_final4(const DevParams& p, int lane,
   load_rows4<fin4_regs(NG)>(p.w_final4, lane, w);
 }
 
-constexpr int kFin4Ahead = 2;   // operand groups in flight ahead of the MFMAs
+#ifndef DDD_FIN4_AHEAD
+#define DDD_FIN4_AHEAD 2   // A/B (profiles/r6_ablation.txt)
+#endif
+constexpr int kFin4Ahead = DDD_FIN4_AHEAD;   // operand groups in flight ahead of the MFMAs
 
 // (TW: the tower -- K taps x C channels: K C / 4 operand groups of four channels,
 // C / 4 per tap row)
@@ -1319,7 +1325,7 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
   for (int og = 0; og < kFin4Ahead; ++og)
     buf[og] = *reinterpret_cast<const f32x4*>(in + off[og / kPerTap] + 16 * (og % kPerTap));
   __builtin_amdgcn_sched_group_barrier(0x100, kFin4Ahead, 0);
-  if (kPrio >= 3) __builtin_amdgcn_s_setprio(0);
+  if (kPrio >= 3) __builtin_amdgcn_s_setprio(kPrio == 5 ? 1 : 0);   // (5, A/B: the 8-cycle MFMA stream one level up)
   fin4_run<NG, TW, kAcc>(in, off, w, buf, acc, std::make_integer_sequence<int, TW::kOperandGroups>{});
   if (kPrio >= 3) __builtin_amdgcn_s_setprio(3);
   // bias row: k = K C against a constant 1
