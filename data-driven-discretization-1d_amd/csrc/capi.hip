@@ -1174,14 +1174,15 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
   }
 #endif
   // nets of up to 16 filters: the block-diagonal tower (float32 state, one-wave groups)
-  const bool half = kRows == 64 && kWR == 64 && !f64 && !traced && eq >= 0 &&
+  const bool half = kRows == 64 && kWR == 64 && !traced && eq >= 0 &&
                     m->d_w_hidden_half != nullptr && m->d_w_final4_half != nullptr && !g_debug.no_half;
   m->last_launch_half = half;
   ddd::DevParams dp_half = m->dp;
   if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; }
 #define DDD_SPEC_CASE(EQ)                                                              \
   case EQ:                                                                             \
-    if (half) ddd::launch::integrate_half_spec<EQ>(dp_half, a, blocks, stream);        \
+    if (half && f64) ddd::launch::integrate_half_f64_spec<EQ>(dp_half, a, blocks, stream); \
+    else if (half) ddd::launch::integrate_half_spec<EQ>(dp_half, a, blocks, stream);   \
     else if (kWR == 16) ddd::launch::integrate_quad_spec<EQ>(m->dp, a, blocks, stream);     \
     else if (kWR == 32) ddd::launch::integrate_split_spec<EQ>(m->dp, a, blocks, stream); \
     else ddd::launch::integrate_spec<EQ>(kRows, f64, traced, m->dp, a, blocks, stream); \
@@ -2523,9 +2524,18 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
     }
     return enqueued();
   }
+  // nets of up to 16 filters: the block-diagonal tower (one-wave groups)
+  const bool half = geo.rows == 64 && m->d_w_hidden_half != nullptr && m->d_w_final4_half != nullptr &&
+                    spec_equation(m, 64) >= 0 && !g_debug.no_half;
+  m->last_launch_half = half;
+  ddd::DevParams dp_half = m->dp;
+  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; }
   switch (spec_equation(m, geo.rows)) {
 #define DDD_ADAPTIVE_CASE(EQ) \
-    case EQ: ddd::launch::adaptive_spec<EQ>(geo.rows, m->dp, a, blocks, stream); break;
+    case EQ:                                                                        \
+      if (half) ddd::launch::adaptive_half_spec<EQ>(dp_half, a, blocks, stream);    \
+      else ddd::launch::adaptive_spec<EQ>(geo.rows, m->dp, a, blocks, stream);      \
+      break;
     DDD_ADAPTIVE_CASE(ddd::EQ_BURGERS)
     DDD_ADAPTIVE_CASE(ddd::EQ_BURGERS_CONS)
     DDD_ADAPTIVE_CASE(ddd::EQ_KDV)

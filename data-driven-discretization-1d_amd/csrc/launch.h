@@ -34,6 +34,10 @@ void integrate_quad_spec(const DevParams& p, const IntegrateArgs& a, int blocks,
 // float32 state): mfma_half.hip, one unit per equation
 template <int kEq>
 void integrate_half_spec(const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream);
+template <int kEq>
+void integrate_half_f64_spec(const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream);
+template <int kEq>
+void adaptive_half_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
 // ... and the adaptive RK23 on the same four-wavefront groups
 template <int kEq>
 void adaptive_quad_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
@@ -66,6 +70,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
   template <> void step_spec<EQ>(int, const DevParams&, const StepArgs&, int, int, hipStream_t); \
   template <> void substep_ring_spec<EQ>(const DevParams&, const RingArgs&, int, hipStream_t); \
   template <> void integrate_half_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
+  template <> void integrate_half_f64_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
+  template <> void adaptive_half_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t); \
   template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void adaptive_quad_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);

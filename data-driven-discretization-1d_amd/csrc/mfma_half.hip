@@ -1,9 +1,10 @@
-// The persistent integrator of the per-equation models on the block-diagonal tower of nets
-// with up to 16 filters (rhs_mfma.h: HalfTower), compiled once per equation id
+// The persistent integrators (fixed step in float32 / float64 state, adaptive RK23) of the
+// per-equation models on the block-diagonal tower of nets with up to 16 filters (rhs_mfma.h: HalfTower), compiled once per equation id
 // (-DDDD_EQ=<0..5>) like mfma_spec.hip.
 #include <hip/hip_runtime.h>
 
 #include "launch.h"
+#include "rhs_adaptive.h"
 #include "rhs_mfma.h"
 
 #ifndef DDD_EQ
@@ -18,6 +19,22 @@ void integrate_half_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int
                                  hipStream_t stream) {
   hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ, false, false, mfma::HalfTower>),
                      dim3(blocks), dim3(64), 0, stream, p, a);
+}
+
+// float64 state (SciPy holds y in float64, integrate.py:154) ...
+template <>
+void integrate_half_f64_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int blocks,
+                                     hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, double, true, DDD_EQ, false, false, mfma::HalfTower>),
+                     dim3(blocks), dim3(64), 0, stream, p, a);
+}
+
+// ... and the production integrator: adaptive RK23, one controller per sample
+template <>
+void adaptive_half_spec<DDD_EQ>(const DevParams& p, const AdaptiveArgs& a, int blocks,
+                                hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ, false, mfma::HalfTower>), dim3(blocks),
+                     dim3(64), 0, stream, p, a);
 }
 
 }  // namespace launch

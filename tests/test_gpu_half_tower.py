@@ -48,9 +48,27 @@ def test_block_diagonal_tower(equation, conservative, overrides):
   ref = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps, steps,
                                y0_host[rows], forcing=sub)
   assert rel_err(got[rows], ref[0]) < TOL
-  # float64 state stays on the embedded route
-  model.integrate_fixed(y0.double(), 2, dt=dt, scheme='midpoint', save_every=2, state_dtype='float64')
-  assert model.kernel_name == 'mfma_f32_r64', model.kernel_name
+  # float64 state and the production integrator (adaptive RK23, integrate.py:143-169) as well;
+  # the four-wave geometry still embeds the net in 32 filters: the same bits, the same nfev
+  y64 = y0.double()
+  f64 = model.integrate_fixed(y64, 6, dt=dt, scheme='bs3', save_every=6, state_dtype='float64')[0]
+  assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
+  span = 12 * dt if equation != 'burgers' else 0.03
+  times = np.linspace(0.0, span, 4)
+  traj, nfev, status = model.integrate_adaptive(y64[:700], times)
+  assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
+  model.set_kernel('mfma256')
+  f64_ref = model.integrate_fixed(y64, 6, dt=dt, scheme='bs3', save_every=6, state_dtype='float64')[0]
+  assert model.kernel_name == 'mfma_f32_r256', model.kernel_name
+  traj_ref, nfev_ref, status_ref = model.integrate_adaptive(y64[:700], times)
+  model.set_kernel('auto')
+  assert torch.equal(f64, f64_ref)
+  assert torch.equal(nfev, nfev_ref) and torch.equal(status, status_ref) and int(status.abs().max()) == 0
+  assert torch.equal(traj, traj_ref)
+  one = None if forcing is None else {k: v[3] for k, v in forcing.items()}
+  ref_traj, ref_nfev = oracle.odeint_rk23(model.spec(), y0_host[3], times, one)
+  assert int(nfev[3]) == ref_nfev
+  assert rel_err(traj[:, 3].cpu().numpy(), ref_traj) < TOL
 
 
 def test_block_diagonal_tower_nan_mask():
