@@ -162,6 +162,10 @@ static_assert(sizeof(Shared<64>) + sizeof(AdaptiveShared<64>) <= 20 * 1024, "8 g
 #ifndef DDD_ADAPTIVE_PREFETCH
 #define DDD_ADAPTIVE_PREFETCH 1   // next output time requested during stage 3
 #endif
+#ifndef DDD_ADAPTIVE_SPECULATE
+#define DDD_ADAPTIVE_SPECULATE 0   // first-stage forcing sums prepared across the error test (round 6):
+                                   // measured neutral (profiles/r6_ablation.txt section 6), off
+#endif
 #ifndef DDD_ADAPTIVE_BUTTERFLY
 #define DDD_ADAPTIVE_BUTTERFLY 1  // ds_bpermute at lane ^ m directly instead of __shfl_xor
 #endif
@@ -243,6 +247,15 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
   int phase = 0;
   int round = 0;
   bool sums_ready = false;   // res.fk_next already holds the forcing sums of this evaluation
+  // One-wave groups also LOOK AHEAD across the error test (round 6): the FSAL stage's evaluation
+  // prepares the sums of the NEXT attempt's first stage for the time that attempt will have if
+  // this one is accepted with the controller saturated at max_step (the Burgers case: every
+  // attempt) -- checked against the real time once the controller has decided, recomputed when
+  // the guess was wrong (a rejection, a step below max_step).  The same instructions on the
+  // same operands as the sums computed in place: the same bits.
+  constexpr bool kSpeculate = kRows == kWR && DDD_ADAPTIVE_SPECULATE;
+  bool sums_guessed = false;
+  float guess_lane = 0.0f;   // the time this lane's (sample, mode) pair was prepared for
   DDD_ADAPT_TRACE_SETUP;
   for (;;) {
     DDD_ADAPT_STAMP(0);
@@ -265,6 +278,7 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
     // of the evaluation before them (as the fixed-step integrators do); the first
     // stage of an attempt cannot: its time depends on the error test.
     const bool ahead = fast_frc && (phase == 2 || phase == 3);
+    bool prepare = ahead;
     float tn_lane = (float)tt;
     if (fast_frc) {
       // the lane's (sample, mode) pair of forcing phase 1 belongs to sample frc_sl of
@@ -279,13 +293,31 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW, true>(
         else if (phase == 3) { ft_now = ft + 0.75 * fh; ft_next = ft + fh; }
         else if (phase == 4) { ft_now = ft + fh; ft_next = ft_now; }
       }
+      if (kSpeculate && sums_guessed) {   // (wave-uniform)
+        const bool wrong = tid < res.frc_pairs && (float)ft_now != guess_lane;
+        sums_ready = __builtin_amdgcn_ballot_w64(wrong) == 0ull;
+        sums_guessed = false;
+      }
       if (!sums_ready)
         res.fk_next = forcing_sums<kRows, kWR, kMaskedSums>(p, sm, res, (float)ft_now, tid);
       tn_lane = (float)ft_next;
+      if (kSpeculate && phase == 4) {
+        // the next attempt of sample frc_sl as Control::advance / begin_step / begin_attempt
+        // will set it up if this one is accepted at h_abs = max_step: t = t_new,
+        // t_new' = min(t + max_step, t_bound), h = t_new' - t; its first stage at t + h / 2
+        const double tp = ctl[frc_sl].t_new;
+        double tq = tp + max_step;
+        if (tq - t_bound > 0.0) tq = t_bound;
+        const double guess = frun ? tp + 0.5 * (tq - tp) : ft;
+        tn_lane = (float)guess;
+        guess_lane = tn_lane;
+        prepare = true;
+        sums_guessed = true;
+      }
     }
     DDD_ADAPT_STAMP(1);
     const float f = eval_rhs<kRows, kWR, kHoist, kEq, false, kWide, adaptive_lean<kRows>(), TW>(
-        p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, ahead);
+        p, sm, a.batch, (float)yy, (float)tt, tn_lane, res, fast_frc, nullptr, nullptr, prepare);
     sums_ready = ahead;
     DDD_ADAPT_STAMP(2);
     if (DDD_ADAPTIVE_SHORTCUT && (phase == 2 || phase == 3)) {
