@@ -446,7 +446,8 @@ DDD_API int ddd_polynomial_accuracy_apply(const float* inputs, const float* null
 /* ---- introspection -------------------------------------------------------*/
 DDD_API int ddd_set_kernel(ddd_model* model, int kernel_kind);
 /* "mfma_f32_r64", "mfma_f32_r64w32", "mfma_f32_r64w16" (small ensembles: every 64-row group
- * on two / four wavefronts), "mfma_f32_r256", "generic", "valu_f32_lean" (fixed
+ * on two / four wavefronts), "mfma_f32_r64h16" (nets of up to 16 filters on the block-diagonal
+ * tower, persistent integrators), "mfma_f32_r256", "generic", "valu_f32_lean" (fixed
  * stencils / one-layer nets, persistent launch: lane == grid point, no matrix work),
  * "valu_f32_weno" (WENO5 + Godunov flux, integrate.py:124-140: one wavefront per sample),
  * "stream_fixed" (fixed stencils, one launch per substep or step) or "spectral_f64":
