@@ -298,6 +298,7 @@ struct ddd_model {
   float* d_w_quad = nullptr;
   float* d_w_hidden_half = nullptr;   // block-diagonal packing of a <= 16-filter net (rhs_mfma.h HalfTower)
   float* d_w_final4_half = nullptr;
+  float* d_w_t16 = nullptr;           // the same net as 16x16x4 A operands (rhs_mfma.h Tile16Tower)
   bool last_launch_half = false;
   bool wide = false;                 // run-time kernels of the wide flavour (rhs_mfma.h kWide)
   bool split_auto = true;            // small ensembles: two 32-row wavefronts per sample (kSplit)
@@ -824,6 +825,24 @@ int pack_mfma_weights(ddd_model* m, const NetLayout& net) {
           }
         rc = upload(quad_rows(fin.data(), fin4_regs(4)), &m->d_w_final4_half);
         if (rc) return rc;
+        // ... and as A operands of the 16x16x4 layers (Tile16Tower): lane l = W[out = l & 15][slot l >> 4];
+        // input layer: step 0 = taps 0..3, step 1 = tap 4, bias, 0, 0; hidden layer: step 4 tap + e,
+        // slot sg -> input channel 4 e + sg; step 20: the bias in slot 0
+        const float* w0 = weights + net.w_off[0];   // [5][1][32]
+        const float* b0 = weights + net.b_off[0];
+        std::vector<float> t16((size_t)(kT16InSteps + kT16HidSteps) * 64, 0.0f);
+        for (int lane = 0; lane < 64; ++lane) {
+          const int sg = lane >> 4, cout = lane & 15;
+          t16[(size_t)0 * 64 + lane] = dn * w0[sg * 32 + cout];
+          t16[(size_t)1 * 64 + lane] = sg == 0 ? dn * w0[4 * 32 + cout] : sg == 1 ? dn * b0[cout] : 0.0f;
+          for (int s2 = 0; s2 < 20; ++s2) {
+            const int tap = s2 / 4, e = s2 % 4;
+            t16[(size_t)(kT16InSteps + s2) * 64 + lane] = w1[(tap * 32 + 4 * e + sg) * 32 + cout];
+          }
+          t16[(size_t)(kT16InSteps + 20) * 64 + lane] = sg == 0 ? dn * b1[cout] : 0.0f;
+        }
+        rc = upload(t16, &m->d_w_t16);
+        if (rc) return rc;
       }
     }
   }
@@ -1178,7 +1197,7 @@ void launch_mfma_integrate(ddd_model* m, const ddd::IntegrateArgs& a, hipStream_
                     m->d_w_hidden_half != nullptr && m->d_w_final4_half != nullptr && !g_debug.no_half;
   m->last_launch_half = half;
   ddd::DevParams dp_half = m->dp;
-  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; }
+  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; dp_half.w_quad = m->d_w_t16; }
 #define DDD_SPEC_CASE(EQ)                                                              \
   case EQ:                                                                             \
     if (half && f64) ddd::launch::integrate_half_f64_spec<EQ>(dp_half, a, blocks, stream); \
@@ -1942,7 +1961,7 @@ int ddd_model_destroy(ddd_model* m) {
   free_dev(m->d_weights); free_dev(m->d_weights4); free_dev(m->d_nullspace); free_dev(m->d_bias);
   free_dev(m->d_w_hidden);
   free_dev(m->d_w_input);
-  free_dev(m->d_w_hidden_half); free_dev(m->d_w_final4_half);
+  free_dev(m->d_w_hidden_half); free_dev(m->d_w_final4_half); free_dev(m->d_w_t16);
   free_dev(m->d_w_final4); free_dev(m->d_w_final4_rt); free_dev(m->d_w_final4_split); free_dev(m->d_w_quad); free_dev(m->d_frc); free_dev(m->d_sp); free_dev(m->d_trig);
   if (m->d_runs != nullptr) (void)hipFree(m->d_runs);
   free_dev(m->d_scratch);
@@ -2529,7 +2548,7 @@ int ddd_integrate_adaptive_f64(ddd_model* m, const double* times, int n_times, d
                     spec_equation(m, 64) >= 0 && !g_debug.no_half;
   m->last_launch_half = half;
   ddd::DevParams dp_half = m->dp;
-  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; }
+  if (half) { dp_half.w_hidden = m->d_w_hidden_half; dp_half.w_final4 = m->d_w_final4_half; dp_half.w_quad = m->d_w_t16; }
   switch (spec_equation(m, geo.rows)) {
 #define DDD_ADAPTIVE_CASE(EQ) \
     case EQ:                                                                        \

@@ -11,13 +11,26 @@
 #error "compile with -DDDD_EQ=<equation id 0..5>"
 #endif
 
+// Which form of the tower the kernels of this unit carry: 1 = 16-channel tiles (Tile16Tower),
+// 0 = the block-diagonal 32x32x2 form (HalfTower); A/B in profiles/r6_ablation.txt.
+#ifndef DDD_HALF_T16
+#define DDD_HALF_T16 1
+#endif
+
 namespace ddd {
+namespace mfma {
+#if DDD_HALF_T16
+typedef Tile16Tower SmallTower;
+#else
+typedef HalfTower SmallTower;
+#endif
+}  // namespace mfma
 namespace launch {
 
 template <>
 void integrate_half_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int blocks,
                                  hipStream_t stream) {
-  hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ, false, false, mfma::HalfTower>),
+  hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, float, true, DDD_EQ, false, false, mfma::SmallTower>),
                      dim3(blocks), dim3(64), 0, stream, p, a);
 }
 
@@ -25,7 +38,7 @@ void integrate_half_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int
 template <>
 void integrate_half_f64_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a, int blocks,
                                      hipStream_t stream) {
-  hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, double, true, DDD_EQ, false, false, mfma::HalfTower>),
+  hipLaunchKernelGGL((mfma::integrate_kernel<64, 64, double, true, DDD_EQ, false, false, mfma::SmallTower>),
                      dim3(blocks), dim3(64), 0, stream, p, a);
 }
 
@@ -33,7 +46,7 @@ void integrate_half_f64_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a,
 template <>
 void adaptive_half_spec<DDD_EQ>(const DevParams& p, const AdaptiveArgs& a, int blocks,
                                 hipStream_t stream) {
-  hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ, false, mfma::HalfTower>), dim3(blocks),
+  hipLaunchKernelGGL((mfma::adaptive_kernel<64, 64, true, DDD_EQ, false, mfma::SmallTower>), dim3(blocks),
                      dim3(64), 0, stream, p, a);
 }
 

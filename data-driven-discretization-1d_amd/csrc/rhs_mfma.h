@@ -96,6 +96,7 @@ struct Tower {
   static constexpr int kOperandGroups = kK_ * kC / 4;   // ds_read_b128 per lane in the output layer
   static constexpr bool kDefault = kK_ == 5 && kCB_ == 1;
   static constexpr bool kHalf = false;              // (HalfTower below)
+  static constexpr bool kTile16 = false;            // (Tile16Tower below)
   // 7 taps x 64 filters: the hidden layer runs as a loop over the taps (hidden_layer_rolled);
   // fully unrolled its 896 MFMAs per layer and kernel took > 20 minutes to compile
   static constexpr bool kRolled = kK_ * kCB_ >= 14;
@@ -119,8 +120,30 @@ struct HalfTower {
   static constexpr int kFinC = 16;
   static constexpr int kFinK = kKW * kFinC + 1;
   static constexpr int kOperandGroups = kKW * kFinC / 4;
-  static constexpr bool kDefault = true, kRolled = false, kHalf = true;
+  static constexpr bool kDefault = true, kRolled = false, kHalf = true, kTile16 = false;
 };
+// ... and the same nets on 16-CHANNEL TILES (round 6): every layer of the
+// tower on v_mfma_f32_16x16x4_f32 -- D[16 channels][16 positions], four position tiles per
+// wavefront, the reduction four (tap, channel) slots per step: no zero blocks at all
+// (hidden layer: 4 x 21 steps of 32 cycles = 2 688 against the block-diagonal form's 5 184).
+//   * LDS rows keep 36 floats, channel c at float 4 (c & 3) + (c >> 2): the hidden layer's B
+//     operand of lane (position j, slot sg) is ONE aligned ds_read_b128 per tap -- channels
+//     sg, 4 + sg, 8 + sg, 12 + sg = the lane's slot in steps 4 tap + 0 .. 3, so the chain of
+//     every output runs over c = 0 .. 15 per tap: the embedded evaluation's order, the same
+//     bits -- and D (lane: channels 4 sg + r) lands with four ds_write_b32 (store_tile16);
+//   * input layer: step 0 = taps 0 .. 3, step 1 = tap 4, bias, 0, 0 (input_layer's k order),
+//     operands by ds_bpermute from the lanes' u / std;
+//   * output layer on the 4x4x1 MFMAs as before (lane == row), its operands four
+//     ds_read_b128 per tap row, picked in natural channel order (final_layer4_t16).
+struct Tile16Tower {
+  static constexpr int kK = kKW, kCB = 1, kC = 32, kHS = 36, kInSteps = 3;
+  static constexpr int kHidK = kKW * 32 / 2, kHidGroups = kHidK / 4;
+  static constexpr int kFinC = 16;
+  static constexpr int kFinK = kKW * kFinC + 1;
+  static constexpr int kOperandGroups = kKW * kFinC / 4;
+  static constexpr bool kDefault = true, kRolled = false, kHalf = false, kTile16 = true;
+};
+constexpr int kT16InSteps = 2, kT16HidSteps = 4 * kKW + 1;   // A-operand rows of DevParams::w_quad in this mode
 // floats of one hidden layer in the streamed layout: [group][out block][lane] float4, then the
 // bias rows [out block][lane]
 template <class TW>
@@ -899,6 +922,79 @@ __device__ __forceinline__ f32x4 final_layer_quad(const float* __restrict__ in,
   return DDD_MFMA16(w[40], 1.0f, acc);   // bias row: k = 160 against a constant 1
 }
 
+// ---- Tile16Tower: a net of <= 16 filters on 16x16x4 tiles, one wavefront per 64-row group ----
+// perm[t][0]: ds_bpermute address of tap (l >> 4)'s row of tile t's position, [t][1]: of tap 4's
+__device__ __forceinline__ void input_layer_t16(float un, float* __restrict__ out,
+                                                const float (&w)[kInSteps], const int (&perm)[4][2],
+                                                const int (&st_off)[4], int act, int lane) {
+  const int uni = __float_as_int(un);
+  float b0[4], b1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    b0[t] = __int_as_float(__builtin_amdgcn_ds_bpermute(perm[t][0], uni));
+    const float tap4 = __int_as_float(__builtin_amdgcn_ds_bpermute(perm[t][1], uni));
+    b1[t] = lane < 16 ? tap4 : 1.0f;   // (slot 1: the bias row; slots 2, 3 carry zero weights)
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[0], b0[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[1], b1[t], acc[t]);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    activate4(acc[t], act);
+    store_tile16(out, st_off[t], acc[t]);
+  }
+}
+
+// hid_off[t][tap]: byte offset of floats 4 sg .. 4 sg + 3 of the tap's row of tile t's position
+template <int kPrio = 0>
+__device__ __forceinline__ void hidden_layer_t16(const float* __restrict__ in, float* __restrict__ out,
+                                                 const float (&w)[kHidSteps], const int (&hid_off)[4][kKW],
+                                                 const int (&st_off)[4], int act) {
+  const char* ib = reinterpret_cast<const char*>(in);
+  f32x4 acc[4];
+  float4 cur[4], nxt[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    acc[t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    cur[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][0]);
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // the reads of tap 0
+#pragma unroll
+  for (int tap = 0; tap < kKW; ++tap) {
+    if (kPrio >= 3 && tap == 1) __builtin_amdgcn_s_setprio(0);
+    if (kPrio >= 3 && tap == kKW - 1) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      nxt[t] = cur[t];
+      if (tap + 1 < kKW) nxt[t] = *reinterpret_cast<const float4*>(ib + hid_off[t][tap + 1]);
+    }
+    // steps 4 tap + e: slot sg carries channel 4 e + sg; four independent accumulators
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[4 * tap + 0], cur[t].x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[4 * tap + 1], cur[t].y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[4 * tap + 2], cur[t].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[4 * tap + 3], cur[t].w, acc[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+    if (tap + 1 < kKW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // reads of tap + 1 first
+    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);                      // the 16 MFMAs of this tap
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = DDD_MFMA16(w[4 * kKW], 1.0f, acc[t]);   // bias: slot 0 carries b[out]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    activate4(acc[t], act);
+    store_tile16(out, st_off[t], acc[t]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Towers other than 5 taps x 32 channels (Tower<7, 1>, <5, 2>, <7, 2>, <3, 1>): the
 // same implicit GEMMs, generic in the tap count and in the number of 32-channel
@@ -1333,6 +1429,54 @@ __device__ __forceinline__ void final_layer4(const float* __restrict__ in_f,
       w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc, std::make_integer_sequence<int, NG>{});
 }
 
+// The output layer of Tile16Tower: lane == row as final_layer4, the row's 16 channels stored at
+// float 4 (c & 3) + (c >> 2) -- four ds_read_b128 per tap row, picked in natural channel order.
+// Weights: the 5 x 16 + 1 reduction rows of HalfTower's packing.
+template <int NG, int kPrio = 0>
+__device__ __forceinline__ void final_layer4_t16(const float* __restrict__ in_f,
+                                                 const float (&w)[fin4_regs_t<Tile16Tower>(NG)],
+                                                 const int (&off)[kKW], f32x4 (&acc)[NG]) {
+  const char* __restrict__ in = reinterpret_cast<const char*>(in_f);
+  f32x4 cur[4], nxt[4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc[g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) cur[q] = *reinterpret_cast<const f32x4*>(in + off[0] + 16 * q);
+  __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+  if (kPrio >= 3) __builtin_amdgcn_s_setprio(kPrio == 5 ? 1 : 0);
+  constexpr int kNW = fin4_regs_t<Tile16Tower>(NG);
+  const auto tap_steps = [&](auto tap_c) {
+    constexpr int tap = decltype(tap_c)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      nxt[q] = cur[q];
+      if (tap + 1 < kKW) nxt[q] = *reinterpret_cast<const f32x4*>(in + off[tap + 1 < kKW ? tap + 1 : tap] + 16 * q);
+    }
+    // channels 4 m .. 4 m + 3 = element m of the four blocks
+    fin4_mfmas<NG, (4 * tap + 0) * 4 * NG, kNW, NG>(w, f32x4{cur[0][0], cur[1][0], cur[2][0], cur[3][0]}, acc,
+                                                 std::make_integer_sequence<int, 4 * NG>{});
+    fin4_mfmas<NG, (4 * tap + 1) * 4 * NG, kNW, NG>(w, f32x4{cur[0][1], cur[1][1], cur[2][1], cur[3][1]}, acc,
+                                                 std::make_integer_sequence<int, 4 * NG>{});
+    fin4_mfmas<NG, (4 * tap + 2) * 4 * NG, kNW, NG>(w, f32x4{cur[0][2], cur[1][2], cur[2][2], cur[3][2]}, acc,
+                                                 std::make_integer_sequence<int, 4 * NG>{});
+    fin4_mfmas<NG, (4 * tap + 3) * 4 * NG, kNW, NG>(w, f32x4{cur[0][3], cur[1][3], cur[2][3], cur[3][3]}, acc,
+                                                 std::make_integer_sequence<int, 4 * NG>{});
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    if (tap + 1 < kKW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 * NG, 0);
+  };
+  tap_steps(std::integral_constant<int, 0>{});
+  tap_steps(std::integral_constant<int, 1>{});
+  tap_steps(std::integral_constant<int, 2>{});
+  tap_steps(std::integral_constant<int, 3>{});
+  tap_steps(std::integral_constant<int, 4>{});
+  if (kPrio >= 3) __builtin_amdgcn_s_setprio(3);
+  // bias row: k = 80 against a constant 1
+  fin4_mfmas<NG, (Tile16Tower::kFinK - 1) * NG, kNW, NG>(
+      w, f32x4{1.0f, 1.0f, 1.0f, 1.0f}, acc, std::make_integer_sequence<int, NG>{});
+}
+
 // Wavefronts per SIMD the kernels are compiled for: two, except the four-wave groups of the
 // 64-channel towers (158 KB of LDS: one workgroup per CU anyway).
 #ifndef DDD_MIN_WAVES_AB
@@ -1364,6 +1508,8 @@ struct Resident {
   float q_in[kQuadInSteps], q_hid[kQuadHidSteps], q_fin[kQuadFinSteps];
   int q_in_off[2][2], q_hid_off[2][kKW], q_fin_off[kKW], q_st_off[2];
   int q_xch_off;            // byte offset (row, channel 4 (l >> 4)) of this lane's output-layer results
+  // Tile16Tower: LDS byte offsets / ds_bpermute addresses of the four 16-position tiles
+  int t16_hid_off[4][kKW], t16_in_perm[4][2], t16_st_off[4];
   float frc_a, frc_omega, frc_phi;   // this lane's (sample, mode) forcing parameters
   float frc_mask[8];        // 1 where entry i of this lane's first 8-mode trip belongs to its run
   float fk_next;            // this lane's harmonic sum for the NEXT evaluation's time
@@ -1641,6 +1787,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     }
     if constexpr (kQuad) {
       input_layer_quad(sm.un, sm.hA, res.q_in, res.q_in_off, res.q_st_off, act, ln.lane);
+    } else if constexpr (TW::kTile16) {
+      static_assert(kKeepOffsets && kWR == 64 && kOneWave, "16-channel tiles: resident one-wave integrators");
+      input_layer_t16(un_reg, sm.hA, res.w_in, res.t16_in_perm, res.t16_st_off, act, ln.lane);
     } else if constexpr (!TW::kDefault) {
       input_layer_big<TW, kWR, kOneWave>(p, ln, sm.un, un_reg, sm.hA, hid_rows, act);
     } else if (!(ablate & 16)) {
@@ -1671,7 +1820,9 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       } else {
         if (!kHoist && l > 1) load_hidden(p, l - 1, ln.lane, res.hid);   // (layer 1: requested above)
         group_barrier<kRows, kWR>();
-        if constexpr (TW::kHalf) {
+        if constexpr (TW::kTile16) {
+          hidden_layer_t16<kPrio>(in, out, res.hid, res.t16_hid_off, res.t16_st_off, act);
+        } else if constexpr (TW::kHalf) {
           static_assert(kKeepOffsets && kWR == 64 && kOneWave, "block-diagonal nets: resident one-wave integrators");
           hidden_layer<32, true, true, kPrio>(p, ln, in, out, res.hid, hid_rows, act, res.st_off);
         } else {
@@ -1788,7 +1939,8 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
       if constexpr (kSpec) {
         f32x4 acc4[kNG];
         if (!(ablate & 4)) {
-          final_layer4<kNG, TW, kNG, kPrio>(in, wf4, off4, acc4);
+          if constexpr (TW::kTile16) final_layer4_t16<kNG, kPrio>(in, wf4, off4, acc4);
+          else final_layer4<kNG, TW, kNG, kPrio>(in, wf4, off4, acc4);
         } else {
 #pragma unroll
           for (int g4 = 0; g4 < kNG; ++g4) acc4[g4] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -2195,9 +2347,24 @@ __device__ __forceinline__ int forcing_batches(const DevParams& p) {
 // (Resident::fin4_off .. pch_idx): functions of the lane, N and G alone.
 // (Loading them from a per-model table instead -- 115 VALU instructions fewer per
 // launch -- changed nothing measurable: profiles/r3_ablation.txt.)
-template <int kRows, int kWR, bool kHalfNet = false>
+template <int kRows, int kWR, bool kHalfNet = false, bool kTile16 = false>
 __device__ __forceinline__ void lane_offsets(const DevParams& p, const Lane& ln, Resident& res) {
   int rows[kKW];
+  if constexpr (kTile16) {
+    static_assert(kRows == 64 && kWR == 64, "16-channel tiles: one-wave groups");
+    const int sg = ln.lane >> 4, j16 = ln.lane & 15;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int trow = 16 * t + j16;
+      tap_rows<true>(ln, trow, p.N, rows);
+#pragma unroll
+      for (int k = 0; k < kKW; ++k)
+        res.t16_hid_off[t][k] = opaque((int)__umul24((unsigned)rows[k], (unsigned)(kHS * 4)) + 16 * sg);
+      res.t16_in_perm[t][0] = opaque(4 * (sg == 0 ? rows[0] : sg == 1 ? rows[1] : sg == 2 ? rows[2] : rows[3]));
+      res.t16_in_perm[t][1] = opaque(4 * rows[4]);
+      res.t16_st_off[t] = opaque((int)__umul24((unsigned)trow, (unsigned)(kHS * 4)) + 4 * sg);
+    }
+  }
   if constexpr (kWR == 16) {
     // four wavefronts per group: tiles of 16 positions, reduction slot sg = lane >> 4
     const int sg = ln.lane >> 4, j16 = ln.lane & 15;
@@ -2315,6 +2482,16 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
         res.q_fin[s2] = wq[(2 * kQuadInSteps + 2 * kQuadHidSteps + s2) * 64];
     }
   } else
+  if constexpr (TW::kTile16) {
+    // A operands of the 16x16x4 layers (DevParams::w_quad in this mode: [2] input rows, [21]
+    // hidden rows of 64 lanes), the output layer's as HalfTower (DevParams::w_final4)
+    const float* __restrict__ wq = p.w_quad + opaque(ln.lane);
+#pragma unroll
+    for (int s2 = 0; s2 < kT16InSteps; ++s2) res.w_in[s2] = wq[s2 * 64];
+#pragma unroll
+    for (int s2 = 0; s2 < kT16HidSteps; ++s2) res.hid[s2] = wq[(kT16InSteps + s2) * 64];
+    load_rows4<fin4_regs(4)>(p.w_final4, ln.lane, res.w_fin4);
+  } else
   if (!p.fixed && !p.linear_taps && TW::kDefault) {   // (other towers stream every layer's weights)
     load_rows4<kInSteps>(p.w_input, ln.lane, res.w_in);
     if (kHoist) load_hidden(p, 0, ln.lane, res.hid);
@@ -2361,7 +2538,7 @@ __device__ __forceinline__ bool setup_weights(const DevParams& p, Shared<kRows, 
   res.fk_off = opaque(ln.sl * kTrigMax * 4);   // (fixed-stencil models with forcing read it too)
   res.st_off = 0;
   if (!p.fixed && !p.linear_taps && kHoist && (kWR == 64 || kWR == 16 || p.w_final4_split != nullptr))
-    lane_offsets<kRows, kWR, TW::kHalf>(p, ln, res);
+    lane_offsets<kRows, kWR, TW::kHalf, TW::kTile16>(p, ln, res);
   // staged (sample, mode) values: zero once, so that reads past a run are finite
   for (int i = tid; i < Shared<kRows, kWR>::kPmMax + 8; i += kThreads)
     sm.pm[i] = make_float2(0.0f, 0.0f);
