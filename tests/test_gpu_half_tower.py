@@ -1,7 +1,7 @@
-"""Nets of up to 16 filters on the block-diagonal tower (csrc/rhs_mfma.h HalfTower, round 6;
-training.py:134-136 leaves filter_size free, model.py:455-458 builds whatever it says): one
-MFMA pass of the hidden layer carries both 32-position tiles of a wavefront.  Same bits as the
-zero-padded embedding in 32 filters (the launch modes that still use it), oracle parity at
+"""Nets of up to 16 filters on 16-channel tiles (csrc/rhs_mfma.h Tile16Tower -- or, built with
+-DDDD_HALF_T16=0, the block-diagonal HalfTower --, round 6; training.py:134-136 leaves
+filter_size free, model.py:455-458 builds whatever it says).  Same bits as the zero-padded
+embedding in 32 filters (the launch modes and geometries that still use it), oracle parity at
 1e-5, NaN mask of the reference."""
 import numpy as np
 import pytest
@@ -12,18 +12,23 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 
-@pytest.mark.parametrize('equation,conservative,overrides', [
-    ('burgers', True, dict(filter_size=16)),
-    ('burgers', False, dict(filter_size=12, kernel_size=3)),
-    ('kdv', True, dict(filter_size=16)),
-    ('kdv', False, dict(filter_size=8)),
-    ('ks', True, dict(filter_size=16, kernel_size=4)),
-    ('ks', False, dict(filter_size=5)),
+@pytest.mark.parametrize('equation,conservative,num_points,overrides', [
+    ('burgers', True, 64, dict(filter_size=16)),
+    ('burgers', False, 64, dict(filter_size=12, kernel_size=3)),
+    ('kdv', True, 64, dict(filter_size=16)),
+    ('kdv', False, 64, dict(filter_size=8)),
+    ('ks', True, 64, dict(filter_size=16, kernel_size=4)),
+    ('ks', False, 64, dict(filter_size=5)),
+    ('burgers', True, 32, dict(filter_size=16)),      # two samples per 64-row group
+    ('kdv', True, 16, dict(filter_size=10)),          # four
+    ('ks', False, 32, dict(filter_size=16, kernel_size=3)),
 ])
-def test_block_diagonal_tower(equation, conservative, overrides):
+def test_block_diagonal_tower(equation, conservative, num_points, overrides):
   import torch
-  model = make_model(equation, conservative, num_points=64, resample_factor=2, **overrides)
-  batch = 2100   # every SIMD holds 64-row wavefronts (small ensembles take the four-wave kernels)
+  model = make_model(equation, conservative, num_points=num_points, resample_factor=2, **overrides)
+  # every SIMD holds 64-row wavefronts (small ensembles take the four-wave kernels); the last
+  # group ragged
+  batch = 2100 * (64 // num_points) + 1
   forcing = batch_forcing(batch) if equation == 'burgers' else None
   if forcing is not None:
     model.set_forcing(forcing)
@@ -55,16 +60,23 @@ def test_block_diagonal_tower(equation, conservative, overrides):
   assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
   span = 12 * dt if equation != 'burgers' else 0.03
   times = np.linspace(0.0, span, 4)
-  traj, nfev, status = model.integrate_adaptive(y64[:700], times)
+  sub = 700 * (64 // num_points)
+  traj, nfev, status = model.integrate_adaptive(y64[:sub], times)
   assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
   model.set_kernel('mfma256')
   f64_ref = model.integrate_fixed(y64, 6, dt=dt, scheme='bs3', save_every=6, state_dtype='float64')[0]
   assert model.kernel_name == 'mfma_f32_r256', model.kernel_name
-  traj_ref, nfev_ref, status_ref = model.integrate_adaptive(y64[:700], times)
+  traj_ref, nfev_ref, status_ref = model.integrate_adaptive(y64[:sub], times)
   model.set_kernel('auto')
   assert torch.equal(f64, f64_ref)
   assert torch.equal(nfev, nfev_ref) and torch.equal(status, status_ref) and int(status.abs().max()) == 0
-  assert torch.equal(traj, traj_ref)
+  if num_points == 64:
+    assert torch.equal(traj, traj_ref)
+  else:
+    # several samples per group: the four-wave geometry sums the error norm's N terms in another
+    # order than the one-wave butterfly (rhs_adaptive.h: sample_sum) -- step sizes differ in
+    # their last bits, the evaluations do not (the fixed-step comparison above is exact)
+    assert torch.allclose(traj, traj_ref, rtol=1e-9, atol=1e-11)
   one = None if forcing is None else {k: v[3] for k, v in forcing.items()}
   ref_traj, ref_nfev = oracle.odeint_rk23(model.spec(), y0_host[3], times, one)
   assert int(nfev[3]) == ref_nfev
