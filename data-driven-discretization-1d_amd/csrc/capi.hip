@@ -1124,8 +1124,16 @@ int launch_substep(ddd_model* m, const ddd::SubstepArgs& a, hipStream_t stream, 
     // each group walks over several row groups (substep_multi_kernel)
     const int grid = std::min(blocks, (geo.rows == 64 ? 2 * device_simds() : device_simds() / 2) /
                                           std::max(grid_share, 1));
+    // nets of up to 16 filters: 16-channel tiles (one-wave groups)
+    const bool half = eq >= 0 && geo.rows == 64 && m->d_w_hidden_half != nullptr &&
+                      m->d_w_final4_half != nullptr && m->d_w_t16 != nullptr && !g_debug.no_half;
+    m->last_launch_half = half;
+    if (half) { dp.w_hidden = m->d_w_hidden_half; dp.w_final4 = m->d_w_final4_half; dp.w_quad = m->d_w_t16; }
 #define DDD_SUBSTEP_CASE(EQ) \
-    case EQ: ddd::launch::substep_spec<EQ>(geo.rows, dp, a, blocks, grid, stream); break;
+    case EQ:                                                                           \
+      if (half) ddd::launch::substep_half_spec<EQ>(dp, a, blocks, grid, stream);       \
+      else ddd::launch::substep_spec<EQ>(geo.rows, dp, a, blocks, grid, stream);       \
+      break;
     switch (eq) {
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS)
       DDD_SUBSTEP_CASE(ddd::EQ_BURGERS_CONS)
@@ -2284,9 +2292,16 @@ int ddd_integrate_fixed(ddd_model* m, int scheme, int launch_mode, double t0, do
         sa.y_in = y + half_off[hf]; sa.y_out = ynew + half_off[hf]; sa.batch = half_batch[hf];
         const int groups = (half_batch[hf] + spg - 1) / spg;
         const int grid = std::min(groups, capacity);
+        const bool half = step_eq >= 0 && geo.rows == 64 && m->d_w_hidden_half != nullptr &&
+                          m->d_w_final4_half != nullptr && m->d_w_t16 != nullptr && !g_debug.no_half;
+        m->last_launch_half = half;
+        if (half) { dp.w_hidden = m->d_w_hidden_half; dp.w_final4 = m->d_w_final4_half; dp.w_quad = m->d_w_t16; }
         switch (step_eq) {
 #define DDD_STEP_CASE(EQ) \
-          case EQ: ddd::launch::step_spec<EQ>(geo.rows, dp, sa, groups, grid, lanes[hf]); break;
+          case EQ:                                                                              \
+            if (half) ddd::launch::step_half_spec<EQ>(dp, sa, groups, grid, lanes[hf]);         \
+            else ddd::launch::step_spec<EQ>(geo.rows, dp, sa, groups, grid, lanes[hf]);         \
+            break;
           DDD_STEP_CASE(ddd::EQ_BURGERS) DDD_STEP_CASE(ddd::EQ_BURGERS_CONS)
           DDD_STEP_CASE(ddd::EQ_KDV) DDD_STEP_CASE(ddd::EQ_KDV_CONS)
           DDD_STEP_CASE(ddd::EQ_KS) DDD_STEP_CASE(ddd::EQ_KS_CONS)

@@ -38,6 +38,10 @@ template <int kEq>
 void integrate_half_f64_spec(const DevParams& p, const IntegrateArgs& a, int blocks, hipStream_t stream);
 template <int kEq>
 void adaptive_half_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
+template <int kEq>
+void substep_half_spec(const DevParams& p, const SubstepArgs& a, int groups, int grid, hipStream_t stream);
+template <int kEq>
+void step_half_spec(const DevParams& p, const StepArgs& a, int groups, int grid, hipStream_t stream);
 // ... and the adaptive RK23 on the same four-wavefront groups
 template <int kEq>
 void adaptive_quad_spec(const DevParams& p, const AdaptiveArgs& a, int blocks, hipStream_t stream);
@@ -72,6 +76,8 @@ void adaptive_spec(int rows, const DevParams& p, const AdaptiveArgs& a, int bloc
   template <> void integrate_half_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_half_f64_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void adaptive_half_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t); \
+  template <> void substep_half_spec<EQ>(const DevParams&, const SubstepArgs&, int, int, hipStream_t); \
+  template <> void step_half_spec<EQ>(const DevParams&, const StepArgs&, int, int, hipStream_t); \
   template <> void integrate_split_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void integrate_quad_spec<EQ>(const DevParams&, const IntegrateArgs&, int, hipStream_t); \
   template <> void adaptive_quad_spec<EQ>(const DevParams&, const AdaptiveArgs&, int, hipStream_t);

@@ -42,6 +42,20 @@ void integrate_half_f64_spec<DDD_EQ>(const DevParams& p, const IntegrateArgs& a,
                      dim3(blocks), dim3(64), 0, stream, p, a);
 }
 
+// one launch per substep / per step (the walks of substep_multi_kernel / step_multi_kernel)
+template <>
+void substep_half_spec<DDD_EQ>(const DevParams& p, const SubstepArgs& a, int groups, int grid,
+                               hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::substep_multi_kernel<64, 64, DDD_EQ, mfma::SmallTower>), dim3(grid), dim3(64), 0,
+                     stream, p, a, groups);
+}
+template <>
+void step_half_spec<DDD_EQ>(const DevParams& p, const StepArgs& a, int groups, int grid,
+                            hipStream_t stream) {
+  hipLaunchKernelGGL((mfma::step_multi_kernel<64, 64, DDD_EQ, mfma::SmallTower>), dim3(grid), dim3(64), 0,
+                     stream, p, a, groups);
+}
+
 // ... and the production integrator: adaptive RK23, one controller per sample
 template <>
 void adaptive_half_spec<DDD_EQ>(const DevParams& p, const AdaptiveArgs& a, int blocks,

@@ -841,6 +841,7 @@ __device__ __forceinline__ void input_layer_quad(const float* __restrict__ un, f
 // hidden layer: this wavefront's 16 output channels x two 16-position tiles.
 // hid_off[t][tap]: byte offset of block (sg & 1, sg >> 1) of the tap's row (the second
 // block, (sg & 1, (sg >> 1) + 2), is 32 bytes on)
+template <int kPrio = 0>
 __device__ __forceinline__ void hidden_layer_quad(const float* __restrict__ in, float* __restrict__ out,
                                                   const float (&w)[kQuadHidSteps],
                                                   const int (&hid_off)[2][kKW], const int (&st_off)[2],
@@ -857,6 +858,8 @@ __device__ __forceinline__ void hidden_layer_quad(const float* __restrict__ in, 
   __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);     // the reads of tap 0
 #pragma unroll
   for (int tap = 0; tap < kKW; ++tap) {
+    if (kPrio >= 3 && tap == 1) __builtin_amdgcn_s_setprio(0);
+    if (kPrio >= 3 && tap == kKW - 1) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       na[t] = ca[t]; nb[t] = cb[t];
@@ -1638,6 +1641,10 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
   const bool pow2 = kRows == 64 || (p.N & (p.N - 1)) == 0;   // N | 64: always; else wave-uniform
   constexpr bool kOneWave = kRows == kWR;   // no other wavefront touches this group's LDS
   constexpr int kPrio = prio_mode(kEq);
+#ifndef DDD_QUAD_PRIO
+#define DDD_QUAD_PRIO 0   // A/B: 3 = the four-wavefront groups' hidden layer lowers its steady middle
+#endif
+  constexpr int kQuadPrio = DDD_QUAD_PRIO;
   // output-channel groups of four (final_layer4): the specialised kernels issue
   // their live ones as one compile-time interleaved stream (channels renumbered
   // contiguously, DevParams::w_final4); the run-time-parameterised kernels
@@ -1807,7 +1814,7 @@ __device__ __forceinline__ float eval_rhs(const DevParams& p, Shared<kRows, kWR,
     for (int l = 1; l < nL - 1; ++l) {
       if constexpr (kQuad) {
         group_barrier<kRows, kWR>();
-        hidden_layer_quad(in, out, res.q_hid, res.q_hid_off, res.q_st_off, act);
+        hidden_layer_quad<kQuadPrio>(in, out, res.q_hid, res.q_hid_off, res.q_st_off, act);
       } else if constexpr (!TW::kDefault) {
         group_barrier<kRows, kWR>();
         if constexpr (TW::kRolled)
@@ -2682,9 +2689,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, (min_waves<kRows, kWR, TW>())) vo
 // L2 traffic per substep at batch 4096 -- and pays a second dispatch round.
 // The walk of one row-group slot: `first` = its first row group, `stride` = the
 // number of slots of the launch.
-template <int kRows, int kWR, int kEq>
+template <int kRows, int kWR, int kEq, class TW = DefaultTower>
 __device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepArgs& a,
-                                             Shared<kRows, kWR>& sm, int groups, int first,
+                                             Shared<kRows, kWR, false, TW>& sm, int groups, int first,
                                              int stride) {
   const int tid = group_tid<kRows, kWR>();
 #ifdef DDD_PROBES
@@ -2767,12 +2774,12 @@ __device__ __forceinline__ void substep_walk(const DevParams& p, const SubstepAr
 #endif
 }
 
-template <int kRows, int kWR, int kEq>
+template <int kRows, int kWR, int kEq, class TW = DefaultTower>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevParams p,
                                                                             SubstepArgs a,
                                                                             int groups) {
-  __shared__ Shared<kRows, kWR> sm;
-  substep_walk<kRows, kWR, kEq>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ Shared<kRows, kWR, false, TW> sm;
+  substep_walk<kRows, kWR, kEq, TW>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // (Several independent one-wave groups per workgroup were measured slower, twice.
@@ -2788,9 +2795,9 @@ __global__ __launch_bounds__(kRows / kWR * 64, 2) void substep_multi_kernel(DevP
 // do not need the substeps (DDD_LAUNCH_PER_STEP): the same walk over row groups
 // with the stage loop of the persistent integrator inside -- the state crosses
 // HBM once per step and the launch boundary is paid once per step.
-template <int kRows, int kWR, int kEq>
+template <int kRows, int kWR, int kEq, class TW = DefaultTower>
 __device__ __forceinline__ void step_walk(const DevParams& p, const StepArgs& a,
-                                          Shared<kRows, kWR>& sm, int groups, int first,
+                                          Shared<kRows, kWR, false, TW>& sm, int groups, int first,
                                           int stride) {
   const int tid = group_tid<kRows, kWR>();
   Lane ln = make_lane<kRows, kWR>(p, a.batch, tid, first);
@@ -2839,11 +2846,11 @@ __device__ __forceinline__ void step_walk(const DevParams& p, const StepArgs& a,
   }
 }
 
-template <int kRows, int kWR, int kEq>
+template <int kRows, int kWR, int kEq, class TW = DefaultTower>
 __global__ __launch_bounds__(kRows / kWR * 64, 2) void step_multi_kernel(DevParams p, StepArgs a,
                                                                          int groups) {
-  __shared__ Shared<kRows, kWR> sm;
-  step_walk<kRows, kWR, kEq>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
+  __shared__ Shared<kRows, kWR, false, TW> sm;
+  step_walk<kRows, kWR, kEq, TW>(p, a, sm, groups, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -38,16 +38,23 @@ def test_block_diagonal_tower(equation, conservative, num_points, overrides):
   steps = 12
   got = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps)[0].cpu().numpy()
   assert model.kernel_name == 'mfma_f32_r64h16', model.kernel_name
-  # the other launch modes run the same net embedded in 32 filters: the same bits
+  # one launch per step / per substep: the same tiles, the same bits ...
   for mode in ('per_step', 'per_substep'):
     other = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
                                   launch_mode=mode)[0].cpu().numpy()
-    assert model.kernel_name == 'mfma_f32_r64', (mode, model.kernel_name)
+    assert model.kernel_name == 'mfma_f32_r64h16', (mode, model.kernel_name)
     np.testing.assert_array_equal(got, other)
   rk4 = model.integrate_fixed(y0, 5, dt=dt, scheme='rk4', save_every=5)[0].cpu().numpy()
-  rk4_step = model.integrate_fixed(y0, 5, dt=dt, scheme='rk4', save_every=5,
-                                   launch_mode='per_step')[0].cpu().numpy()
-  np.testing.assert_array_equal(rk4, rk4_step)
+  # ... and the four-wave geometry, which still embeds the net in 32 filters
+  model.set_kernel('mfma256')
+  for mode in ('persistent', 'per_step'):
+    other = model.integrate_fixed(y0, steps, dt=dt, scheme='midpoint', save_every=steps,
+                                  launch_mode=mode)[0].cpu().numpy()
+    assert model.kernel_name == 'mfma_f32_r256', (mode, model.kernel_name)
+    np.testing.assert_array_equal(got, other)
+  rk4_ref = model.integrate_fixed(y0, 5, dt=dt, scheme='rk4', save_every=5)[0].cpu().numpy()
+  model.set_kernel('auto')
+  np.testing.assert_array_equal(rk4, rk4_ref)
   rows = np.array([0, 1, batch // 2, batch - 1])
   sub = None if forcing is None else {k: v[rows] for k, v in forcing.items()}
   ref = oracle.integrate_fixed(model.spec(), oracle.SCHEME_MIDPOINT, 0.0, dt, steps, steps,
@@ -96,8 +103,9 @@ def test_block_diagonal_tower_nan_mask():
   dt = model.equation.time_step
   got = model.integrate_fixed(y0, 1, dt=dt, scheme='euler', save_every=1)[0].cpu().numpy()
   assert model.kernel_name == 'mfma_f32_r64h16'
-  other = model.integrate_fixed(y0, 1, dt=dt, scheme='euler', save_every=1,
-                                launch_mode='per_step')[0].cpu().numpy()
+  model.set_kernel('mfma256')   # (embedded in 32 filters)
+  other = model.integrate_fixed(y0, 1, dt=dt, scheme='euler', save_every=1)[0].cpu().numpy()
+  model.set_kernel('auto')
   np.testing.assert_array_equal(np.isnan(got), np.isnan(other))
   assert np.isnan(got[7]).any() and not np.isnan(np.delete(got, 7, axis=0)).any()
   np.testing.assert_array_equal(got[~np.isnan(got)], other[~np.isnan(other)])
