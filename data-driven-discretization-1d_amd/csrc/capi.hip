@@ -1483,7 +1483,11 @@ void ring_destroy(ddd_model* m) {
   }
   rg->cv.notify_all();
   rg->parker.join();
-  if (rg->stream != nullptr) (void)hipStreamSynchronize(rg->stream);   // the kernel reads the ring until it ends
+  // the kernel reads the ring until it ends (a stream the caller has already destroyed: the device)
+  if (rg->stream == nullptr || hipStreamSynchronize(rg->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+  }
   (void)hipHostFree(rg->slots);
   (void)hipHostFree(rg->done);
   (void)hipFree(rg->d_count);
