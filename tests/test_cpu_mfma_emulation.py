@@ -679,3 +679,121 @@ def test_quad_flavour_reduction_order_is_the_one_wavefront_kernels():
   assert [4 * s + sg for s in range(40) for sg in range(4)] == list(range(160))
   # input layer: (tap 0, tap 1), (tap 2, tap 3), (tap 4, bias)  ==  (taps 0..3), (tap 4, bias, 0, 0)
   assert [2 * s + h for s in range(3) for h in (0, 1)] == [0, 1, 2, 3, 4, 5]
+
+
+# ---------------------------------------------------------------------------
+# Nets of up to 16 filters on 16-channel tiles (rhs_mfma.h Tile16Tower, round 6): ONE wavefront
+# per 64-row group, every layer of the tower on v_mfma_f32_16x16x4_f32, four position tiles.
+# Transcribes capi.hip's d_w_t16 / d_w_final4_half packing, lane_offsets<..., kTile16>,
+# input_layer_t16 / hidden_layer_t16 / final_layer4_t16.
+# ---------------------------------------------------------------------------
+def t16_channel_float(c):      # position of channel c (< 16) in an LDS row
+  return 4 * (c & 3) + (c >> 2)
+
+
+def pack_t16(kernels, biases, dn):
+  """capi.hip: [2] input + [21] hidden rows x 64 lanes from the net EMBEDDED in 32 filters."""
+  w0, b0, w1, b1 = kernels[0], biases[0], kernels[1], biases[1]
+  rows = np.zeros((2 + 21, 64))
+  for lane in range(64):
+    sg, cout = lane >> 4, lane & 15
+    rows[0, lane] = dn * w0[sg, 0, cout]
+    rows[1, lane] = dn * w0[4, 0, cout] if sg == 0 else dn * b0[cout] if sg == 1 else 0.0
+    for s2 in range(20):
+      tap, e = s2 // 4, s2 % 4
+      rows[2 + s2, lane] = w1[tap, 4 * e + sg, cout]
+    rows[2 + 20, lane] = dn * b1[cout] if sg == 0 else 0.0
+  return rows
+
+
+def emulate_tower_t16(un64, n, kernels, biases, n_ch, relu_shift=RELU_SHIFT):
+  """kernels / biases: the net embedded in 5 taps x 32 filters (channels >= 16 zero)."""
+  dn, up = np.ldexp(1.0, -relu_shift), np.ldexp(1.0, relu_shift)
+  relu = (lambda x: np.clip(x, 0.0, 1.0)) if relu_shift else (lambda x: np.maximum(x, 0.0))
+  wq = pack_t16(kernels, biases, dn)
+  hA, hB = np.full((64, HS), np.nan), np.full((64, HS), np.nan)
+  sg, j16 = LANES >> 4, LANES & 15
+
+  def tap_row(trow, off):
+    base = trow & ~(n - 1)
+    return ((trow + off) & (n - 1)) | base
+
+  def store16(buf, trow, acc):   # lane (j, sg) holds channels 4 sg + r -> float 4 r + sg (store_tile16 at + 4 sg)
+    for r in range(4):
+      buf[trow, 4 * r + sg] = acc[:, r]
+      assert (t16_channel_float(4 * sg + r) == 4 * r + sg).all()
+
+  for t in range(4):             # input layer: taps 0..3 | tap 4, bias, 0, 0
+    trow = 16 * t + j16
+    b0 = un64[tap_row(trow, sg - 2)]
+    b1 = np.where(LANES < 16, un64[tap_row(trow, 2)], 1.0)
+    acc = np.zeros((64, 4))
+    acc = mfma16(wq[0], b0, acc)
+    acc = mfma16(wq[1], b1, acc)
+    store16(hA, trow, relu(acc))
+  for t in range(4):             # hidden layer: step 4 tap + e, slot sg = channel 4 e + sg
+    trow = 16 * t + j16
+    acc = np.zeros((64, 4))
+    for tap in range(5):
+      rows = tap_row(trow, tap - 2)
+      for e in range(4):         # ONE ds_read_b128 at float 4 sg: elements e = 0..3
+        bop = hA[rows, 4 * sg + e]
+        assert (4 * sg + e == t16_channel_float(4 * e + sg)).all()
+        acc = mfma16(wq[2 + 4 * tap + e], bop, acc)
+    acc = mfma16(wq[2 + 20], np.ones(64), acc)
+    store16(hB, trow, relu(acc))
+  # output layer on the 4x4x1 MFMAs, lane == row: four float4 blocks per tap row, channels
+  # picked in natural order: channel c = element (c >> 2) of block (c & 3)
+  w_flat = kernels[2].reshape(5, 32, -1)
+  net = np.zeros((64, 16))
+  rows64 = np.arange(64)
+  for ch in range(n_ch):
+    acc = np.zeros(64)
+    for tap in range(5):
+      src = tap_row(rows64, tap - 2)
+      for c in range(16):
+        acc = acc + up * w_flat[tap, c, ch] * hB[src, 4 * (c & 3) + (c >> 2)]
+    net[:, ch] = acc + biases[2][ch]
+  return net
+
+
+@pytest.mark.parametrize('n,filters,c_out', [(64, 16, 12), (32, 12, 9), (16, 5, 14), (8, 16, 11)])
+def test_tile16_data_movement(n, filters, c_out):
+  """The 16-channel tiles compute the tower the oracle's conv stack computes for the TRUE net
+  (and the one-wavefront emulation for its embedding in 32 filters)."""
+  rs = np.random.RandomState(7 * n + filters + c_out)
+  true_shapes = [(5, 1, filters), (5, filters, filters), (5, filters, c_out)]
+  kernels = [rs.randn(*s).astype(np.float32) * 0.3 for s in true_shapes]
+  biases = [rs.randn(s[2]).astype(np.float32) * 0.1 for s in true_shapes]
+  emb_k = [np.zeros((5, 1, 32), np.float32), np.zeros((5, 32, 32), np.float32),
+           np.zeros((5, 32, c_out), np.float32)]
+  emb_b = [np.zeros(32, np.float32), np.zeros(32, np.float32), biases[2]]
+  emb_k[0][:, :, :filters] = kernels[0]
+  emb_k[1][:, :filters, :filters] = kernels[1]
+  emb_k[2][:, :filters, :] = kernels[2]
+  emb_b[0][:filters] = biases[0]
+  emb_b[1][:filters] = biases[1]
+  samples = 64 // n
+  u = rs.randn(samples, n).astype(np.float32)
+  un = (u / np.float32(0.8)).reshape(-1).astype(np.float64)
+  got = emulate_tower_t16(un, n, emb_k, emb_b, c_out)
+  spec = dict(standard_deviation=0.8, conv_kernels=kernels, conv_biases=biases,
+              num_layers=3, nonlinearity='relu')
+  want = oracle.conv_stack(u, spec).reshape(64, c_out)
+  np.testing.assert_allclose(got[:, :c_out], want, rtol=2e-4, atol=2e-5)
+  un_rows = np.zeros(ROWS)
+  un_rows[:64] = un
+  one = emulate_tower(un_rows, n, emb_k, emb_b, c_out)[:64]
+  np.testing.assert_allclose(got[:, :c_out], one[:, :c_out], rtol=1e-9, atol=1e-12)
+
+
+def test_tile16_reduction_order_is_the_embedded_evaluations():
+  """Bit-identity with the zero-padded embedding rests on the order of every fma chain."""
+  # hidden layer, embedded one-wavefront kernel: step 16 tap + jj, slots cin = jj, 16 + jj; the
+  # channels >= 16 carry zero weights and zero activations: what remains is c = 0..15 per tap
+  embedded = [(tap, c) for tap in range(5) for c in range(16)]
+  # tiles: step 4 tap + e, slots sg = 0..3: channel 4 e + sg
+  tiles = [(s // 4, 4 * (s % 4) + sg) for s in range(20) for sg in range(4)]
+  assert tiles == embedded
+  # output layer: k = 16 tap + c in natural order, operand = element c >> 2 of block c & 3
+  assert sorted(4 * (c & 3) + (c >> 2) for c in range(16)) == list(range(16))
